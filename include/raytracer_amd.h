@@ -1,0 +1,298 @@
+/*
+ * raytracer_amd.h - C ABI of the MI355X (gfx950) ray tracing hot path.
+ *
+ * The reference (/root/reference) is pure Python and has no FFI; the functions below
+ * are what a binding for its per-sample path would bind.  Each entry point names the
+ * reference seam it stands behind.  Conventions:
+ *
+ *   - every function returns 0 on success and a negative RTAMD_E* code on failure;
+ *     rtamd_last_error() returns a message for the calling thread's last failure;
+ *   - scene tables and sample/ray/result buffers are DEVICE pointers owned by the
+ *     caller (e.g. torch tensors' data_ptr()); descriptors (structs below) are HOST
+ *     memory and are copied during the call;
+ *   - launches are asynchronous on the hipStream_t passed as `stream` (a void* here so
+ *     that the header needs no HIP include); results are valid once that stream has
+ *     been synchronised;
+ *   - nothing is allocated per call; a scene handle owns one small device block that
+ *     lives until rtamd_scene_destroy;
+ *   - a handle belongs to the device that was current in rtamd_scene_create; calls on
+ *     one handle must not overlap in time on different streams if they share outputs.
+ *
+ * All geometry and shading arithmetic is IEEE double ("f64"), like the reference's
+ * Python floats.
+ */
+#ifndef RAYTRACER_AMD_H
+#define RAYTRACER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTAMD_ABI_VERSION 1
+
+enum {
+    RTAMD_OK = 0,
+    RTAMD_EINVAL = -1,      /* bad argument / inconsistent descriptor          */
+    RTAMD_EUNSUPPORTED = -2,/* valid scene the device path does not cover     */
+    RTAMD_EHIP = -3,        /* a HIP runtime call failed                      */
+    RTAMD_ENODEVICE = -4    /* no gfx950 device available                     */
+};
+
+/* primitive kinds of world.objects entries (geometry.py classes) */
+enum {
+    RTAMD_SPHERE = 0,        /* Sphere / ConcaveSphere   geometry.py:245-307 */
+    RTAMD_PLANE = 1,         /* Plane                    geometry.py:310-336 */
+    RTAMD_CHECKER_PLANE = 2, /* CheckerPlane             geometry.py:339-363 */
+    RTAMD_RECTANGLE = 3,     /* Rectangle                geometry.py:365-416 */
+    RTAMD_BOX = 4,           /* AxisAlignedBox           geometry.py:115-242 */
+    RTAMD_TRIANGLE = 5,      /* Triangle                 geometry.py:419-473 */
+    RTAMD_KDTREE = 6         /* KDTree                   kdtree.py:55-174    */
+};
+
+/* material kinds (material.py) */
+enum {
+    RTAMD_MATTE = 0, RTAMD_PHONG = 1, RTAMD_REFLECTIVE = 2,
+    RTAMD_GLOSSY_REFLECTIVE = 3, RTAMD_EMISSIVE = 4
+};
+
+/* light kinds (light.py) */
+enum { RTAMD_POINT = 0, RTAMD_DIRECTIONAL = 1, RTAMD_AREA = 2, RTAMD_ENVIRONMENT = 3 };
+enum { RTAMD_AMBIENT_CONSTANT = 0, RTAMD_AMBIENT_OCCLUDER = 1 };
+
+/* tracer kinds (tracer.py:21-88) */
+enum { RTAMD_TRACER_SHADE = 0, RTAMD_TRACER_AREA = 1, RTAMD_TRACER_PATH = 2 };
+
+/* One entry of world.objects, in list order (main.py:35-46 scans them in that order and
+ * the earlier object wins ties).  `p` holds the primitive's parameters:
+ *   SPHERE     center[3], radius, normal_sign
+ *   PLANE      point[3], normal[3]
+ *   CHECKER    point[3], normal[3], right[3], up[3], grid_size
+ *   RECTANGLE  p0[3], normal[3], right[3], top[3], a, b
+ *   BOX        lo[3], hi[3]
+ *   TRIANGLE   v0[3], v1[3], v2[3], normal[3], n0[3], n1[3], n2[3] (n* only if smooth)
+ *   KDTREE     -  (see `tree`)
+ * With has_transform the object is an Instance (geometry.py:85-112): `inv_point` is the
+ * upper 3x4 of inverse(M) row-major, `inv_dir` is inverse(M[:3,:3]) row-major (the
+ * reference inverts the two separately). */
+typedef struct rtamd_object {
+    int32_t kind;
+    int32_t material;       /* index into materials; -1 for KDTREE                */
+    int32_t alt_material;   /* CheckerPlane's second material                     */
+    int32_t cast_shadow;
+    int32_t has_transform;
+    int32_t tree;           /* index into trees for KDTREE, else -1               */
+    int32_t smooth;         /* TRIANGLE: vertex normals present                   */
+    int32_t reserved;
+    double p[30];
+    double inv_point[12];
+    double inv_dir[9];
+    double pad_;            /* keeps sizeof a multiple of 16                       */
+} rtamd_object;
+
+typedef struct rtamd_material {
+    int32_t kind;
+    int32_t receives_shadow;
+    int32_t sampler;        /* glossy lobe / path tracing hemisphere sampler, or -1 */
+    int32_t reserved;
+    double ambient[3];      /* ka*cd            material.py:55-56                 */
+    double diffuse[3];      /* kd*cd/pi         material.py:38-39                 */
+    double specular[3];     /* ks*cs            material.py:95                    */
+    double exp;
+    double reflect[3];      /* kr*cd            material.py:74 / :121             */
+    double reflect_exp;
+    double emit[3];         /* ls*color         material.py:492-493               */
+    double pad_;
+} rtamd_material;
+
+typedef struct rtamd_light {
+    int32_t kind;
+    int32_t cast_shadow;
+    int32_t sampler;        /* AREA / ENVIRONMENT                                  */
+    int32_t reserved;
+    double radiance[3];     /* ls*color, or the emitter's Le                       */
+    double position[3];     /* POINT location, DIRECTIONAL direction, AREA corner  */
+    double attenuation;
+    double radius;
+    double edge_u[3];       /* AREA: sample = corner + sx*edge_u + sy*edge_v       */
+    double edge_v[3];
+    double normal[3];       /* AREA emitter normal                                 */
+    double pdf;             /* AREA: 1/area as the shape reports it                */
+} rtamd_light;
+
+typedef struct rtamd_ambient {
+    int32_t kind;
+    int32_t sampler;        /* OCCLUDER hemisphere sampler                         */
+    double radiance[3];     /* ls*color                                            */
+    double occluded[3];     /* 0.1*ls*color    light.py:97-98                      */
+} rtamd_ambient;
+
+/* One sampler object's tables inside `sampler_data` (doubles):
+ *   square:  num_patterns * samples_per_pattern * 2   (sampler.py:31)
+ *   disk:    same shape                                (sampler.py:34-61)
+ *   hemi:    num_patterns * samples_per_pattern * 3   (sampler.py:63-76)
+ * `regular` marks a RegularSampler, whose methods consume no random draw. */
+typedef struct rtamd_sampler {
+    int32_t num_patterns;
+    int32_t samples_per_pattern;
+    int32_t regular;
+    int32_t reserved;
+    int64_t square_offset;
+    int64_t disk_offset;
+    int64_t hemi_offset;
+} rtamd_sampler;
+
+/* 16-byte kd node; nodes of a tree are stored in preorder, so the left child of node i
+ * is node i+1.  Interior: split plane, a = index of the right child, b = axis (0..2).
+ * Leaf: b & 3 == 3, a = first leaf reference, b >> 2 = reference count.
+ * Node and reference indices are absolute (into kd_nodes / tri_* of the scene). */
+typedef struct rtamd_kdnode {
+    double split;
+    int32_t a;
+    int32_t b;
+} rtamd_kdnode;
+
+typedef struct rtamd_tree {
+    double bbox_lo[3];
+    double bbox_hi[3];
+    int32_t node_offset;    /* root node index in kd_nodes                         */
+    int32_t ref_offset;     /* first leaf reference of this tree in tri_* arrays   */
+    int32_t prim_offset;    /* first primitive of this tree in prim_* arrays       */
+    int32_t smooth;         /* vertex normals present: prim_normals holds 9/prim   */
+    int32_t depth;          /* maximum node depth (stack bound)                    */
+    int32_t reserved[3];
+} rtamd_tree;
+
+/* Everything a render needs that does not change between frames.
+ * Leaf-ordered triangle tables have one row per leaf reference (a triangle that
+ * straddles a split plane appears once per leaf that holds it, kdtree.py:52):
+ *   tri_geom[ref][9]  = v0, v1-v0, v2-v0
+ *   tri_prim[ref]     = primitive index within its tree; bit 30 set if the triangle
+ *                       does not cast shadows (geometry.py:433-434)
+ * Per-primitive tables (one row per triangle, all trees concatenated):
+ *   prim_normals      = unit face normal [3], or n0,n1,n2 [9] for smooth trees; rows
+ *                       are addressed through prim_normal_offset[prim] (in doubles)
+ *   prim_material[prim]
+ */
+typedef struct rtamd_scene_desc {
+    int32_t abi_version;
+    int32_t tracer_kind;
+    int32_t depth_limit;
+    int32_t n_objects;
+    int32_t n_materials;
+    int32_t n_lights;
+    int32_t n_samplers;
+    int32_t n_trees;
+    int64_t n_kd_nodes;
+    int64_t n_refs;
+    int64_t n_prims;
+    int64_t n_sampler_doubles;
+    double background[3];
+    rtamd_ambient ambient;
+    const rtamd_object *objects;        /* device */
+    const rtamd_material *materials;    /* device */
+    const rtamd_light *lights;          /* device */
+    const rtamd_sampler *samplers;      /* device */
+    const double *sampler_data;         /* device */
+    const rtamd_tree *trees;            /* device */
+    const rtamd_kdnode *kd_nodes;       /* device */
+    const double *tri_geom;             /* device */
+    const int32_t *tri_prim;            /* device */
+    const double *prim_normals;         /* device */
+    const int64_t *prim_normal_offset;  /* device */
+    const int32_t *prim_material;       /* device */
+} rtamd_scene_desc;
+
+/* Camera and view plane (camera.py:12-33, :142-146, :222-225; tracer.py:91-95). */
+typedef struct rtamd_camera {
+    double eye[3], u[3], v[3], w[3];
+    double viewing_distance;
+    double lens_radius;
+    double focal_plane_distance;
+    double pixel_size;
+    int32_t thin_lens;
+    int32_t width, height;
+    int32_t sampler;        /* view-plane sampler index                            */
+} rtamd_camera;
+
+/* Per-sample results; any pointer may be NULL to skip that output.
+ *   rgb[n][3]     radiance before quantisation (what trace_ray returns)
+ *   rgb8[n][3]    int(c*255) per channel, as camera.py:66 emits (not clamped)
+ *   hit_object[n] index into world.objects of the primary hit, -1 on a miss
+ *   hit_prim[n]   triangle index within its tree (face index after quad split), else -1
+ *   hit_t[n]      primary tmin
+ *   n_rays[n][2]  closest-hit queries (main.py:35 calls) and shadow queries
+ *                 (light in_shadow calls) spent on the sample */
+typedef struct rtamd_sample_out {
+    double *rgb;
+    int32_t *rgb8;
+    int32_t *hit_object;
+    int32_t *hit_prim;
+    double *hit_t;
+    int32_t *n_rays;
+} rtamd_sample_out;
+
+/* Launch-wide counters, added to by every launch that is given the block:
+ *   [0] closest-hit queries   [1] shadow queries      [2] samples traced
+ *   [3] kd interior steps     [4] kd leaves visited   [5] triangle tests
+ *   [6] analytic object tests [7] reserved
+ * [3]-[6] are only maintained by rtamd_*_counted variants (flags & RTAMD_COUNT_WORK). */
+#define RTAMD_N_COUNTERS 8
+#define RTAMD_COUNT_WORK 1u
+
+typedef struct rtamd_scene rtamd_scene;
+
+/* Library / device check.  Fails with RTAMD_ENODEVICE when no HIP device is usable. */
+int rtamd_abi_version(void);
+int rtamd_device_check(void);
+const char *rtamd_last_error(void);
+
+/* Scene lifetime.  Stands where World.__init__ leaves a built, immutable world
+ * (main.py:13-22); validates the descriptor (counts, index ranges read on the host are
+ * limited to the descriptor itself - table contents are trusted). */
+int rtamd_scene_create(const rtamd_scene_desc *desc, rtamd_scene **out);
+int rtamd_scene_destroy(rtamd_scene *scene);
+
+/* camera.render_pixels(world, pairs)  (camera.py:60-67, :227-234): trace n samples whose
+ * view-plane points the caller chose.  pixel_index[n] = row*width+col and sample_index[n]
+ * key the in-trace random draws; plane_points[n][3]; lens_points[n][3] for a thin-lens
+ * camera (NULL otherwise). */
+int rtamd_render_pixels(rtamd_scene *scene, const rtamd_camera *camera, uint64_t seed,
+                        int64_t n, const int32_t *pixel_index, const int32_t *sample_index,
+                        const double *plane_points, const double *lens_points,
+                        const rtamd_sample_out *out, uint64_t *counters, uint32_t flags,
+                        void *stream);
+
+/* world.tracer.trace_ray(ray, depth)  (tracer.py:26-35, :65-71, :79-88): trace n explicit
+ * rays starting at recursion depth `depth`. */
+int rtamd_trace_rays(rtamd_scene *scene, uint64_t seed, int64_t n,
+                     const int32_t *pixel_index, const int32_t *sample_index,
+                     const double *origins, const double *directions, int32_t depth,
+                     const rtamd_sample_out *out, uint64_t *counters, uint32_t flags,
+                     void *stream);
+
+/* Whole-frame sample generation + trace for a list of 8x8-pixel tiles: the work of
+ * get_pixel_plane_point_pairs + render_pixels (camera.py:69-98, :236-267, :60-67) for the
+ * pixels of those tiles and sample indices [sample_begin, sample_end) of each pixel's
+ * pattern.  tile_ids[n_tiles] index tiles row-major over ceil(width/8) x ceil(height/8).
+ * Sample k of the launch is (tile k / (64*ns), sample k / 64 % ns, pixel-in-tile k % 64),
+ * pixel-in-tile = 8*dy + dx; results for pixels outside the image are not written.
+ *   per_sample: optional per-sample outputs in that order (may be NULL)
+ *   sum_rgb8[n_tiles*64][3]  int64: += int(c*255) per sample (numerator of parallel mode's
+ *                             running mean, main.py:99-103), row = 64*position of the tile
+ *                             in tile_ids + pixel-in-tile
+ *   sum_sq[n_tiles*64][3]    double: += c*c per sample (camera.py:55, :135), same rows
+ * Either accumulator may be NULL; both are added to, so the caller zeroes them and may
+ * split a frame's samples over several calls with the same tile list. */
+int rtamd_render_tiles(rtamd_scene *scene, const rtamd_camera *camera, uint64_t seed,
+                       int64_t n_tiles, const int32_t *tile_ids,
+                       int32_t sample_begin, int32_t sample_end,
+                       const rtamd_sample_out *per_sample,
+                       int64_t *sum_rgb8, double *sum_sq,
+                       uint64_t *counters, uint32_t flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACER_AMD_H */

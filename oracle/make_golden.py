@@ -1,0 +1,382 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF on seeded inputs.
+
+TEST INFRASTRUCTURE - not part of the product.  Runs only in the build container, where
+/root/reference exists; the .npz files it writes are the committed fixtures.
+
+What it does
+  1. copies /root/reference/*.py and buildfunctions/ into a temp dir and converts that
+     copy from Python 2 with `python3 -m lib2to3 -w -n` (nothing from the copy is kept);
+  2. puts an empty `pygame` module in front of main.py's import, empties the copy's
+     buildfunctions/__init__.py (py2 implicit-relative imports), links the asset dirs;
+  3. replaces `random.choice/shuffle/uniform` with the counter-based draws of
+     raytracer_amd/rng.py and points the draw context at (pixel, sample) before every
+     call into the reference - the reference code itself is not modified;
+  4. wraps `hit` methods to learn which primitive produced a ShadeRecord, and
+     `hit_objects` / `in_shadow` to count rays;
+  5. loads the scene files of raytracer_amd/scenes/ (they import the scene API by the
+     reference's top-level module names, so here they bind to the reference's classes),
+     traces a sparse seeded pixel set through `camera.ray_direction` +
+     `world.tracer.trace_ray`, exactly what `camera.render_pixels` does per pair
+     (camera.py:60-67), and records inputs and outputs.
+
+Usage: python oracle/make_golden.py [scene ...]
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+import types
+
+import numpy
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = "/root/reference"
+GOLDEN = os.path.join(REPO, "tests", "golden")
+SEED = 1
+
+sys.path.insert(0, REPO)
+from raytracer_amd import rng  # noqa: E402  (pure python, no scene API import)
+
+# scene -> (viewmode, overrides, number of sparse samples, extra dense window or None)
+PLAN = {
+    "foursphere":       ("parallel", None, 6000),
+    "glossyreflective": ("parallel", None, 6000),
+    "mirrorhall":       ("parallel", None, 6000),
+    "mirrorhall_dof":   ("parallel", dict(resolution=(384, 216), sample_dim=8), 6000),
+    "cornellbox":       ("parallel", None, 3000),
+    "cornellbox_area":  ("parallel", None, 4000),
+    "j":                ("parallel", None, 2500),
+    "dragon_area":      ("parallel", dict(resolution=(480, 270), sample_dim=4), 1500),
+    "features_analytic": ("parallel", None, 6000),
+    "features_mesh":    ("parallel", None, 3000),
+    "features_env":     ("parallel", None, 4000),
+}
+
+
+def convert_reference():
+    tmp = tempfile.mkdtemp(prefix="rt_ref_py3_")
+    for name in os.listdir(REFERENCE):
+        if name.endswith(".py"):
+            shutil.copy(os.path.join(REFERENCE, name), tmp)
+    shutil.copytree(os.path.join(REFERENCE, "buildfunctions"), os.path.join(tmp, "buildfunctions"))
+    subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", tmp],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    open(os.path.join(tmp, "buildfunctions", "__init__.py"), "w").close()
+    for d in ("meshes", "CornellBox"):
+        os.symlink(os.path.join(REFERENCE, d), os.path.join(tmp, d))
+    return tmp
+
+
+class Harness(object):
+    def __init__(self):
+        self.tmp = convert_reference()
+        sys.path.insert(0, os.path.join(self.tmp, "buildfunctions"))
+        sys.path.insert(0, self.tmp)
+        sys.modules["pygame"] = types.ModuleType("pygame")
+        sys.setrecursionlimit(10000)
+        os.chdir(self.tmp)
+        import random
+        random.choice, random.shuffle, random.uniform = rng.choice, rng.shuffle, rng.uniform
+        import main, geometry, kdtree, light  # noqa: E401  (the converted reference)
+        self.main, self.geometry, self.kdtree, self.light = main, geometry, kdtree, light
+        self.n_closest = self.n_shadow = 0
+        self._wrap()
+
+    def close(self):
+        os.chdir(REPO)
+        shutil.rmtree(self.tmp, ignore_errors=True)
+
+    def _wrap(self):
+        G, K, L = self.geometry, self.kdtree, self.light
+        harness = self
+
+        def tag_hits(cls):
+            orig = cls.__dict__["hit"]
+
+            def hit(obj, ray):
+                sr = orig(obj, ray)
+                if sr is not None:
+                    sr._prim = obj
+                return sr
+            cls.hit = hit
+        for cls in (G.Sphere, G.Plane, G.CheckerPlane, G.Rectangle, G.AxisAlignedBox, G.Triangle):
+            tag_hits(cls)
+
+        orig_init = K.BoundingBoxes.__init__
+
+        def bb_init(obj, boxes):
+            for i, box in enumerate(boxes):
+                if not hasattr(box.obj, "_gid"):
+                    box.obj._gid = i
+            orig_init(obj, boxes)
+        K.BoundingBoxes.__init__ = bb_init
+
+        orig_hit_objects = self.main.World.hit_objects
+
+        def hit_objects(world, ray):
+            harness.n_closest += 1
+            return orig_hit_objects(world, ray)
+        self.main.World.hit_objects = hit_objects
+
+        def count_shadow(cls):
+            orig = cls.__dict__["in_shadow"]
+
+            def in_shadow(obj, ray, sr):
+                harness.n_shadow += 1
+                return orig(obj, ray, sr)
+            cls.in_shadow = in_shadow
+        for cls in (L.PointLight, L.DirectionLight, L.AmbientOccluder, L.AreaLight, L.EnvironmentLight):
+            count_shadow(cls)
+
+    # -- scene -----------------------------------------------------------------------
+    def build(self, scene, viewmode, overrides):
+        import importlib.util
+        import buildfunctionbase
+        scene_dir = os.path.join(REPO, "raytracer_amd", "scenes")
+        for fname in sorted(os.listdir(scene_dir)):
+            if fname.endswith(".py"):
+                modname = "golden_scene_" + fname[:-3]
+                if modname not in sys.modules:
+                    spec = importlib.util.spec_from_file_location(modname, os.path.join(scene_dir, fname))
+                    mod = importlib.util.module_from_spec(spec)
+                    sys.modules[modname] = mod
+                    spec.loader.exec_module(mod)
+        fcn = buildfunctionbase.BuildFunctionBase.get_build_function(scene)
+        world = self.main.World.__new__(self.main.World)
+        if overrides:
+            world.overrides = overrides
+        rng.context.reseed(SEED)
+        devnull = open(os.devnull, "w")
+        stdout, sys.stdout = sys.stdout, devnull          # the reference prints every node size
+        try:
+            fcn(world, viewmode)
+        finally:
+            sys.stdout = stdout
+            devnull.close()
+        world.fast, world.numcores, world.breakon = False, 1, None
+        return world
+
+    def primary_ids(self, world, ray):
+        """(object index, primitive index, tmin) of the closest hit, by the rule of main.py:35-46."""
+        tmin, best = self.main.INF, (-1, -1, 0.0)
+        for idx, obj in enumerate(world.objects):
+            sr = obj.hit(ray)
+            if sr and sr.tmin < tmin:
+                tmin = sr.tmin
+                best = (idx, getattr(sr._prim, "_gid", -1), float(sr.tmin))
+        return best
+
+    def trace_samples(self, world, pixels, samples):
+        import tracer as T
+        cam, vp = world.camera, world.viewplane
+        w, h = vp.resolution
+        thin = hasattr(cam, "lens_radius")
+        n = len(pixels)
+        rec = dict(
+            pixel=numpy.asarray(pixels, dtype=numpy.int32), sample=numpy.asarray(samples, dtype=numpy.int32),
+            plane_point=numpy.zeros((n, 3)), lens_point=numpy.zeros((n, 3)),
+            origin=numpy.zeros((n, 3)), direction=numpy.zeros((n, 3)),
+            hit_object=numpy.full(n, -1, numpy.int32), hit_prim=numpy.full(n, -1, numpy.int32),
+            hit_t=numpy.zeros(n), rgb=numpy.zeros((n, 3)), rgb8=numpy.zeros((n, 3), numpy.int64),
+            n_rays=numpy.zeros((n, 2), numpy.int32), ok=numpy.zeros(n, numpy.bool_))
+        t0 = time.time()
+        for i in range(n):
+            col, row = pixels[i]
+            s = samples[i]
+            pix = row * w + col
+            rng.context.point(rng.PHASE_PIXEL, pix, 0, 0)
+            pattern = vp.sampler.sample()
+            disk = vp.sampler.sample_unit_disk() if thin else None
+            sample = pattern[s]
+            plane_point = numpy.zeros(3)
+            plane_point[0] = vp.pixel_size * (col - w // 2 + sample[0])
+            plane_point[1] = vp.pixel_size * (row - h // 2 + sample[1])
+            if thin:
+                lens_point = cam.eye + numpy.array([disk[s][0], disk[s][1], 0.0]) * cam.lens_radius
+                direction = cam.ray_direction(plane_point, lens_point)
+                ray = T.Ray(lens_point, direction)
+                rec["lens_point"][i] = lens_point
+            else:
+                direction = cam.ray_direction(plane_point)
+                ray = T.Ray(cam.eye, direction)
+            rec["plane_point"][i] = plane_point
+            rec["origin"][i], rec["direction"][i] = ray.origin, ray.direction
+            rng.context.point(rng.PHASE_TRACE, pix, s, 0)
+            self.n_closest = self.n_shadow = 0
+            try:
+                with numpy.errstate(all="ignore"):
+                    color = numpy.array(world.tracer.trace_ray(ray), dtype=numpy.float64)
+                rec["rgb"][i] = color
+                rec["n_rays"][i] = (self.n_closest, self.n_shadow)
+                with numpy.errstate(all="ignore"):
+                    rec["hit_object"][i], rec["hit_prim"][i], rec["hit_t"][i] = self.primary_ids(world, ray)
+                if numpy.all(numpy.isfinite(color)):
+                    # camera.py:66; Python ints are unbounded, the device clamps to int32
+                    rec["rgb8"][i] = [max(-2 ** 31, min(2 ** 31 - 1, int(c * 255))) for c in color]
+                    rec["ok"][i] = True
+            except numpy.linalg.LinAlgError:
+                pass            # singular triangle system: the reference worker dies here
+            if (i + 1) % 500 == 0:
+                print("    %d/%d samples, %.1fs" % (i + 1, n, time.time() - t0), flush=True)
+        return rec
+
+
+def choose_samples(world, count, seed):
+    w, h = world.viewplane.resolution
+    n_samples = len(world.viewplane.sampler.sample())
+    r = numpy.random.RandomState(seed)
+    cols = r.randint(0, w, count)
+    rows = r.randint(0, h, count)
+    # bias half of the picks towards the image centre, where the scene content is
+    k = count // 2
+    cols[:k] = numpy.clip(r.normal(w / 2, w / 6, k).astype(int), 0, w - 1)
+    rows[:k] = numpy.clip(r.normal(h / 2, h / 6, k).astype(int), 0, h - 1)
+    samples = r.randint(0, n_samples, count)
+    return list(zip(cols.tolist(), rows.tolist())), samples.tolist()
+
+
+def sampler_tables(sampler):
+    if not hasattr(sampler, "patterns"):
+        return {}
+    return dict(square=numpy.array(sampler.patterns, dtype=numpy.float64),
+                disk=numpy.array(sampler.concentric_patterns, dtype=numpy.float64),
+                hemi=numpy.array(sampler.hemisphere_patterns, dtype=numpy.float64))
+
+
+def tree_record(harness, world):
+    """Preorder description of every kd-tree in world.objects, in the reference's own terms."""
+    import hashlib
+    out = {}
+    k = 0
+    for obj in world.objects:
+        tree = getattr(obj, "obj", obj)
+        if not isinstance(tree, harness.kdtree.KDTree):
+            continue
+        h = hashlib.sha256()
+        stats = dict(nodes=0, leaves=0, refs=0, depth=0, max_leaf=0)
+
+        def walk(node, depth):
+            stats["nodes"] += 1
+            stats["depth"] = max(stats["depth"], depth)
+            if node.leaf_items:
+                stats["leaves"] += 1
+                stats["refs"] += len(node.leaf_items)
+                stats["max_leaf"] = max(stats["max_leaf"], len(node.leaf_items))
+                h.update(("L" + ",".join(b.obj.label for b in node.leaf_items) + ";").encode())
+            else:
+                h.update(("I%d:%s;" % (node.split_idx, float(node.split_center).hex())).encode())
+                walk(node.left, depth + 1)
+                walk(node.right, depth + 1)
+        walk(tree, 0)
+        out["tree%d_signature" % k] = numpy.array(h.hexdigest())
+        out["tree%d_stats" % k] = numpy.array([stats[x] for x in ("nodes", "leaves", "refs", "depth", "max_leaf")])
+        k += 1
+    return out
+
+
+def frame_order_golden(harness):
+    """The producer of camera.py:69-98 / :236-267 run on a tiny frame: chunk sizes, pixel
+    order and view-plane points, with per-pixel draws keyed as the device keys them."""
+    out = {}
+    for scene, overrides in (("cornellbox_area", dict(resolution=(8, 6), sample_dim=2)),
+                             ("mirrorhall_dof", dict(resolution=(8, 6), sample_dim=2))):
+        world = harness.build(scene, "parallel", overrides)
+        vp = world.viewplane
+        state = dict(pixel=-1)
+        orig_sample, orig_disk = vp.sampler.sample, vp.sampler.sample_unit_disk
+
+        def sample():
+            state["pixel"] += 1
+            rng.context.point(rng.PHASE_PIXEL, state["pixel"], 0, 0)
+            return orig_sample()
+
+        def disk():
+            rng.context.point(rng.PHASE_PIXEL, state["pixel"], 0, 1)
+            return orig_disk()
+        vp.sampler.sample, vp.sampler.sample_unit_disk = sample, disk
+        import random
+        orig_shuffle = random.shuffle
+
+        def shuffle(lst):
+            rng.context.point(rng.PHASE_FRAME, 0, 0)
+            orig_shuffle(lst)
+        random.shuffle = shuffle
+        try:
+            chunks = list(world.camera.get_pixel_plane_point_pairs(world, 10))
+        finally:
+            random.shuffle = orig_shuffle
+            vp.sampler.sample, vp.sampler.sample_unit_disk = orig_sample, orig_disk
+        out[scene + "_chunk_sizes"] = numpy.array([len(c) for c in chunks])
+        flat = [p for c in chunks for p in c]
+        out[scene + "_pixels"] = numpy.array([p[0] for p in flat], dtype=numpy.int32)
+        if isinstance(flat[0][1], tuple):
+            out[scene + "_plane_points"] = numpy.array([p[1][0] for p in flat])
+            out[scene + "_lens_points"] = numpy.array([p[1][1] for p in flat])
+        else:
+            out[scene + "_plane_points"] = numpy.array([p[1] for p in flat])
+    return out
+
+
+def render_mode_golden(harness):
+    """camera.render (camera.py:35-58) on a tiny frame: the integer triples handed to pixel_func."""
+    world = harness.build("cornellbox_area", "parallel", dict(resolution=(8, 6), sample_dim=2))
+    vp = world.viewplane
+    w = vp.resolution[0]
+    state = dict(pixel=-1, sample=0)
+    orig_sample = vp.sampler.sample
+    orig_trace = world.tracer.trace_ray
+
+    def sample():
+        state["pixel"] += 1
+        state["sample"] = 0
+        rng.context.point(rng.PHASE_PIXEL, state["pixel"], 0, 0)
+        return orig_sample()
+
+    def trace_ray(ray, depth=0):
+        if depth == 0:
+            rng.context.point(rng.PHASE_TRACE, state["pixel"], state["sample"], 0)
+            state["sample"] += 1
+        return orig_trace(ray, depth)
+    vp.sampler.sample = sample
+    world.tracer.trace_ray = trace_ray
+    got = []
+    with numpy.errstate(all="ignore"):
+        world.camera.render(world, lambda coord, r, g, b: got.append((coord[0], coord[1], r, g, b)))
+    return dict(render_pixels=numpy.array(got, dtype=numpy.int64))
+
+
+def main(argv):
+    scenes = argv or list(PLAN)
+    os.makedirs(GOLDEN, exist_ok=True)
+    harness = Harness()
+    try:
+        for scene in scenes:
+            if scene == "frame_order":
+                numpy.savez_compressed(os.path.join(GOLDEN, "frame_order.npz"), **frame_order_golden(harness),
+                                       **render_mode_golden(harness))
+                print("frame_order written")
+                continue
+            viewmode, overrides, count = PLAN[scene]
+            t0 = time.time()
+            world = harness.build(scene, viewmode, overrides)
+            print("%s: built in %.1fs" % (scene, time.time() - t0), flush=True)
+            pixels, samples = choose_samples(world, count, seed=1234)
+            rec = harness.trace_samples(world, pixels, samples)
+            rec.update({"sampler_" + k: v for k, v in sampler_tables(world.viewplane.sampler).items()})
+            rec.update(tree_record(harness, world))
+            rec["resolution"] = numpy.array(world.viewplane.resolution)
+            rec["overrides"] = numpy.array(repr(overrides))
+            rec["viewmode"] = numpy.array(viewmode)
+            rec["seed"] = numpy.array(SEED)
+            numpy.savez_compressed(os.path.join(GOLDEN, scene + ".npz"), **rec)
+            print("%s: %d samples (%d ok) in %.1fs, rays/sample %.2f" % (
+                scene, count, int(rec["ok"].sum()), time.time() - t0, rec["n_rays"].sum() / float(count)), flush=True)
+    finally:
+        harness.close()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

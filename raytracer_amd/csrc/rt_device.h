@@ -1,0 +1,648 @@
+// Per-sample ray tracing path for gfx950, IEEE double throughout.
+//
+// Every function states the reference code it reproduces (paths under
+// /root/reference).  Comparisons are written in the reference's own form and order
+// (`not t > eps`, strict `<`, Python's min/max argument rules) because NaN and
+// infinities from zero direction components flow through them.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/raytracer_amd.h"
+
+namespace rt {
+
+constexpr double EPS = 1.0e-7;                    // geometry.py:8, tracer.py:4, kdtree.py:5
+constexpr double T_INF = 9223372036854775807.0;   // sys.maxint, the initial tmin (main.py:37)
+constexpr double PI = 3.141592653589793;
+constexpr int STACK_MAX = 64;                     // >= tree depth + 2, checked on the host
+constexpr int NO_SHADOW_BIT = 1 << 30;
+
+// ---------------------------------------------------------------- small vector type
+struct V3 { double x, y, z; };
+
+__device__ __forceinline__ V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld3(const double* p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 operator/(V3 a, double s) { return v3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ double norm(V3 a) { return sqrt(dot(a, a)); }
+__device__ __forceinline__ double axis_of(V3 a, int ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z); }
+
+// Python's min/max keep the first argument unless a later one compares strictly
+// beyond it; with NaN operands that is not fmin/fmax.
+__device__ __forceinline__ double pymin(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double pymax(double a, double b) { return (b > a) ? b : a; }
+
+struct Ray { V3 o, d; };
+
+// ---------------------------------------------------------------- random draws
+// Same function as raytracer_amd/rng.py: draw = mix(mix(mix(seed ^ phase*C) ^ a) ^ (b<<32 | counter)).
+constexpr uint64_t PHASE_MUL = 0xD6E8FEB86659FD93ull;
+constexpr uint64_t PHASE_PIXEL = 2, PHASE_TRACE = 4;
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t phase_key(uint64_t seed, uint64_t phase) {
+    return mix64(seed ^ (phase * PHASE_MUL));
+}
+__device__ __forceinline__ uint32_t index_from(uint64_t h, uint32_t n) {
+    return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32);
+}
+
+struct Draw {
+    uint64_t key;       // mix(phase_key ^ pixel index)
+    uint32_t sample;
+    uint32_t counter;
+    __device__ __forceinline__ uint32_t index(uint32_t n) {
+        uint64_t h = mix64(key ^ (((uint64_t)sample << 32) | (uint64_t)counter));
+        counter++;
+        return index_from(h, n);
+    }
+};
+
+// sampler.py:84-85 (one uniform choice over the flat hemisphere list); a RegularSampler
+// returns its single vector without drawing (sampler.py:13-14).
+__device__ __forceinline__ V3 draw_hemisphere(const rtamd_scene_desc& S, int sid, Draw& dr) {
+    const rtamd_sampler sm = S.samplers[sid];
+    uint32_t i = sm.regular ? 0u : dr.index((uint32_t)(sm.num_patterns * sm.samples_per_pattern));
+    return ld3(S.sampler_data + sm.hemi_offset + 3 * (int64_t)i);
+}
+
+// geometry.py:379: random.choice(sampler.sample()) - pattern choice, then element choice.
+__device__ __forceinline__ void draw_square(const rtamd_scene_desc& S, int sid, Draw& dr, double& sx, double& sy) {
+    const rtamd_sampler sm = S.samplers[sid];
+    uint32_t pat = sm.regular ? 0u : dr.index((uint32_t)sm.num_patterns);
+    uint32_t el = dr.index((uint32_t)sm.samples_per_pattern);
+    const double* p = S.sampler_data + sm.square_offset + 2 * ((int64_t)pat * sm.samples_per_pattern + el);
+    sx = p[0];
+    sy = p[1];
+}
+
+// ---------------------------------------------------------------- work counters
+template <bool COUNT> struct Work {
+    uint32_t closest = 0, shadow = 0;
+    __device__ __forceinline__ void node() {}
+    __device__ __forceinline__ void leaf() {}
+    __device__ __forceinline__ void tri(uint32_t) {}
+    __device__ __forceinline__ void analytic() {}
+    __device__ __forceinline__ uint32_t nodes() const { return 0; }
+    __device__ __forceinline__ uint32_t leaves() const { return 0; }
+    __device__ __forceinline__ uint32_t tris() const { return 0; }
+    __device__ __forceinline__ uint32_t analytics() const { return 0; }
+};
+template <> struct Work<true> {
+    uint32_t closest = 0, shadow = 0, n_node = 0, n_leaf = 0, n_tri = 0, n_analytic = 0;
+    __device__ __forceinline__ void node() { n_node++; }
+    __device__ __forceinline__ void leaf() { n_leaf++; }
+    __device__ __forceinline__ void tri(uint32_t k) { n_tri += k; }
+    __device__ __forceinline__ void analytic() { n_analytic++; }
+    __device__ __forceinline__ uint32_t nodes() const { return n_node; }
+    __device__ __forceinline__ uint32_t leaves() const { return n_leaf; }
+    __device__ __forceinline__ uint32_t tris() const { return n_tri; }
+    __device__ __forceinline__ uint32_t analytics() const { return n_analytic; }
+};
+
+// ---------------------------------------------------------------- triangles
+// geometry.py:447-455 solves [v1-v0, v2-v0, -d] (alpha, beta, t)^T = o - v0 with LAPACK.
+// Here the same system is solved by Cramer's rule in the Moeller-Trumbore arrangement;
+// a singular system (the reference raises) is a miss because every comparison with
+// the resulting inf/NaN is false.
+__device__ __forceinline__ bool tri_solve(const double* __restrict__ g, const Ray& r,
+                                          double& alpha, double& beta, double& t) {
+    const V3 v0 = ld3(g), e1 = ld3(g + 3), e2 = ld3(g + 6);
+    const V3 pvec = cross(r.d, e2);
+    const double det = dot(e1, pvec);
+    const double inv = 1.0 / det;
+    const V3 tvec = r.o - v0;
+    alpha = dot(tvec, pvec) * inv;
+    const V3 qvec = cross(tvec, e1);
+    beta = dot(r.d, qvec) * inv;
+    t = dot(e2, qvec) * inv;
+    return alpha > EPS && beta > EPS && t > EPS && alpha + beta < 1.0;
+}
+
+// ---------------------------------------------------------------- kd-tree
+struct KdStackEntry { int32_t node; double t_near, t_far; };
+
+// BoundingBox.hit (geometry.py:49-70) on the tree's root box.
+__device__ __forceinline__ bool root_box(const rtamd_tree& T, const Ray& r, double& tmin, double& tmax) {
+    const double dx = 1.0 / r.d.x, dy = 1.0 / r.d.y, dz = 1.0 / r.d.z;
+    const double t1 = (T.bbox_lo[0] - r.o.x) * dx, t2 = (T.bbox_hi[0] - r.o.x) * dx;
+    const double t3 = (T.bbox_lo[1] - r.o.y) * dy, t4 = (T.bbox_hi[1] - r.o.y) * dy;
+    const double t5 = (T.bbox_lo[2] - r.o.z) * dz, t6 = (T.bbox_hi[2] - r.o.z) * dz;
+    tmin = pymax(pymax(pymin(t1, t2), pymin(t3, t4)), pymin(t5, t6));
+    tmax = pymin(pymin(pymax(t1, t2), pymax(t3, t4)), pymax(t5, t6));
+    if (tmax < 0) return false;
+    if (tmin > tmax) return false;
+    return true;
+}
+
+// Front-to-back leaf walk of KDTree.iterate_nodes (kdtree.py:133-155).  `LeafFn(first,
+// count)` returns true to stop the walk (the closest-hit and shadow queries both stop at
+// the first leaf that yields a hit).
+template <bool COUNT, class LeafFn>
+__device__ __forceinline__ void kd_walk(const rtamd_scene_desc& S, const rtamd_tree& T, const Ray& r,
+                                        Work<COUNT>& w, LeafFn&& leaf_fn) {
+    double t_near, t_far;
+    if (!root_box(T, r, t_near, t_far)) return;
+    KdStackEntry stack[STACK_MAX];
+    int sp = 0;
+    int32_t node = T.node_offset;
+    for (;;) {
+        rtamd_kdnode nd = S.kd_nodes[node];
+        while ((nd.b & 3) != 3) {
+            w.node();
+            const int ax = nd.b;
+            const double o = axis_of(r.o, ax), d = axis_of(r.d, ax);
+            const double t = (nd.split - o) / d;
+            int32_t near_n, far_n;
+            if (nd.split >= o) { near_n = node + 1; far_n = nd.a; }
+            else               { near_n = nd.a;     far_n = node + 1; }
+            if (t >= t_far || t < 0) {
+                node = near_n;
+            } else if (t <= t_near) {
+                node = far_n;
+            } else {
+                stack[sp].node = far_n; stack[sp].t_near = t; stack[sp].t_far = t_far;
+                sp++;
+                node = near_n;
+                t_far = t;
+            }
+            nd = S.kd_nodes[node];
+        }
+        w.leaf();
+        if (leaf_fn(nd.a, nd.b >> 2)) return;
+        if (sp == 0) return;
+        sp--;
+        node = stack[sp].node; t_near = stack[sp].t_near; t_far = stack[sp].t_far;
+    }
+}
+
+struct TriHit { double t, alpha, beta; int32_t ref; };
+
+// KDTree.hit (kdtree.py:166-174): all items of a leaf are tested, the strict minimum t
+// wins (first item on ties), and the walk ends at the first leaf that produced a hit.
+template <bool COUNT>
+__device__ __forceinline__ bool kd_closest(const rtamd_scene_desc& S, const rtamd_tree& T, const Ray& r,
+                                           Work<COUNT>& w, TriHit& best) {
+    bool found = false;
+    kd_walk<COUNT>(S, T, r, w, [&](int32_t first, int32_t count) {
+        w.tri((uint32_t)count);
+        for (int32_t i = 0; i < count; ++i) {
+            double a, b, t;
+            if (tri_solve(S.tri_geom + 9 * (int64_t)(first + i), r, a, b, t)) {
+                if (!found || best.t > t) { best.t = t; best.alpha = a; best.beta = b; best.ref = first + i; found = true; }
+            }
+        }
+        return found;
+    });
+    return found;
+}
+
+// KDTree.shadow_hit (kdtree.py:157-164): the first item, in leaf order, that reports a
+// hit ends the query; its t is returned whatever the caller's distance bound is.
+template <bool COUNT>
+__device__ __forceinline__ bool kd_shadow(const rtamd_scene_desc& S, const rtamd_tree& T, const Ray& r,
+                                          Work<COUNT>& w, double& t_out) {
+    bool found = false;
+    kd_walk<COUNT>(S, T, r, w, [&](int32_t first, int32_t count) {
+        for (int32_t i = 0; i < count; ++i) {
+            if (S.tri_prim[first + i] & NO_SHADOW_BIT) continue;     // geometry.py:433-434
+            w.tri(1);
+            double a, b, t;
+            if (tri_solve(S.tri_geom + 9 * (int64_t)(first + i), r, a, b, t)) { t_out = t; found = true; return true; }
+        }
+        return false;
+    });
+    return found;
+}
+
+// ---------------------------------------------------------------- analytic primitives
+// Sphere.hit / shadow_hit share this root selection (geometry.py:253-296).
+__device__ __forceinline__ bool sphere_t(const double* p, const Ray& r, V3& temp, double& t) {
+    temp = r.o - ld3(p);
+    const double a = dot(r.d, r.d);
+    const double b = 2.0 * dot(temp, r.d);
+    const double c = dot(temp, temp) - p[3] * p[3];
+    const double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) return false;
+    const double e = sqrt(disc);
+    const double denom = 2.0 * a;
+    t = (-b - e) / denom;
+    if (!(t > EPS)) t = (-b + e) / denom;
+    return t > EPS;
+}
+
+// Plane.hit (geometry.py:317-326); also the first half of CheckerPlane / Rectangle.
+__device__ __forceinline__ bool plane_t(V3 point, V3 normal, const Ray& r, double& t) {
+    const double dn = dot(r.d, normal);
+    if (dn == 0) return false;
+    t = dot(point - r.o, normal) / dn;
+    return t > EPS;
+}
+
+// Rectangle.hit / shadow_hit (geometry.py:388-416): p0 is the centre here.
+__device__ __forceinline__ bool rectangle_t(const double* p, const Ray& r, double& t) {
+    if (!plane_t(ld3(p), ld3(p + 3), r, t)) return false;
+    const V3 diff = (r.o + t * r.d) - ld3(p);
+    const double a = fabs(dot(diff, ld3(p + 6)));
+    const double b = fabs(dot(diff, ld3(p + 9)));
+    return a * 2 <= p[12] && b * 2 <= p[13];
+}
+
+// AxisAlignedBox.hit (geometry.py:136-217).
+__device__ __forceinline__ bool box_hit(const double* p, const Ray& r, double& tmin, V3& normal) {
+    const double dx = 1.0 / r.d.x, dy = 1.0 / r.d.y, dz = 1.0 / r.d.z;
+    double tx_min, tx_max, ty_min, ty_max, tz_min, tz_max;
+    if (dx >= 0) { tx_min = (p[0] - r.o.x) * dx; tx_max = (p[3] - r.o.x) * dx; }
+    else         { tx_min = (p[3] - r.o.x) * dx; tx_max = (p[0] - r.o.x) * dx; }
+    if (dy >= 0) { ty_min = (p[1] - r.o.y) * dy; ty_max = (p[4] - r.o.y) * dy; }
+    else         { ty_min = (p[4] - r.o.y) * dy; ty_max = (p[1] - r.o.y) * dy; }
+    if (dz >= 0) { tz_min = (p[2] - r.o.z) * dz; tz_max = (p[5] - r.o.z) * dz; }
+    else         { tz_min = (p[5] - r.o.z) * dz; tz_max = (p[2] - r.o.z) * dz; }
+    double t0, t1;
+    int face_in, face_out;
+    if (tx_min > ty_min) { t0 = tx_min; face_in = (dx >= 0) ? 0 : 3; }
+    else                 { t0 = ty_min; face_in = (dy >= 0) ? 1 : 4; }
+    if (tz_min > t0)     { t0 = tz_min; face_in = (dz >= 0) ? 2 : 5; }
+    if (tx_max < ty_max) { t1 = tx_max; face_out = (dx >= 0) ? 3 : 0; }
+    else                 { t1 = ty_max; face_out = (dy >= 0) ? 4 : 1; }
+    if (tz_max < t1)     { t1 = tz_max; face_out = (dz >= 0) ? 5 : 2; }
+    if (t0 < t1 && t1 > EPS) {
+        int face;
+        if (t0 > EPS) { tmin = t0; face = face_in; }
+        else          { tmin = t1; face = face_out; }
+        const double s = face < 3 ? -1.0 : 1.0;          // FACE_ARRAY, geometry.py:116-121
+        const int ax = face % 3;
+        normal = v3(ax == 0 ? s : 0.0, ax == 1 ? s : 0.0, ax == 2 ? s : 0.0);
+        return true;
+    }
+    return false;
+}
+
+// AxisAlignedBox.shadow_hit (geometry.py:219-242): a different slab form that reports
+// the entry distance even when it is negative.
+__device__ __forceinline__ bool box_shadow(const double* p, const Ray& r, double& t) {
+    const double dx = 1.0 / r.d.x, dy = 1.0 / r.d.y, dz = 1.0 / r.d.z;
+    const double t1 = (p[0] - r.o.x) * dx, t2 = (p[3] - r.o.x) * dx;
+    const double t3 = (p[1] - r.o.y) * dy, t4 = (p[4] - r.o.y) * dy;
+    const double t5 = (p[2] - r.o.z) * dz, t6 = (p[5] - r.o.z) * dz;
+    const double tmin = pymax(pymax(pymin(t1, t2), pymin(t3, t4)), pymin(t5, t6));
+    const double tmax = pymin(pymin(pymax(t1, t2), pymax(t3, t4)), pymax(t5, t6));
+    if (tmax < EPS) return false;
+    if (tmin > tmax) return false;
+    t = tmin;
+    return true;
+}
+
+// Instance.inv_ray (geometry.py:97-101): the direction is not renormalised.
+__device__ __forceinline__ Ray to_object_space(const rtamd_object& ob, const Ray& r) {
+    const double* m = ob.inv_point;
+    const double* n = ob.inv_dir;
+    Ray q;
+    q.o = v3(((m[0] * r.o.x + m[1] * r.o.y) + m[2] * r.o.z) + m[3],
+             ((m[4] * r.o.x + m[5] * r.o.y) + m[6] * r.o.z) + m[7],
+             ((m[8] * r.o.x + m[9] * r.o.y) + m[10] * r.o.z) + m[11]);
+    q.d = v3((n[0] * r.d.x + n[1] * r.d.y) + n[2] * r.d.z,
+             (n[3] * r.d.x + n[4] * r.d.y) + n[5] * r.d.z,
+             (n[6] * r.d.x + n[7] * r.d.y) + n[8] * r.d.z);
+    return q;
+}
+// Instance.hit (geometry.py:107): normal through the transposed inverse, not renormalised.
+__device__ __forceinline__ V3 normal_to_world(const rtamd_object& ob, V3 nrm) {
+    const double* n = ob.inv_dir;
+    return v3((n[0] * nrm.x + n[3] * nrm.y) + n[6] * nrm.z,
+              (n[1] * nrm.x + n[4] * nrm.y) + n[7] * nrm.z,
+              (n[2] * nrm.x + n[5] * nrm.y) + n[8] * nrm.z);
+}
+
+// ---------------------------------------------------------------- world queries
+struct Hit {
+    double t;
+    V3 n;        // shading normal as the primitive reports it
+    V3 p;        // hit_point = origin + tmin*direction (main.py:44)
+    int32_t material, object, prim;
+};
+
+// World.hit_objects (main.py:35-46): objects in list order, strict `<`.
+template <bool COUNT>
+__device__ bool closest_hit(const rtamd_scene_desc& S, const Ray& ray, Work<COUNT>& w, Hit& h) {
+    w.closest++;
+    double tmin = T_INF;
+    bool any = false;
+    for (int i = 0; i < S.n_objects; ++i) {
+        const rtamd_object& ob = S.objects[i];
+        const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+        const double* p = ob.p;
+        double t = 0;
+        V3 n = v3(0, 0, 0);
+        int32_t mat = ob.material, prim = -1;
+        bool hit = false;
+        if (ob.kind != RTAMD_KDTREE) w.analytic();
+        switch (ob.kind) {
+        case RTAMD_SPHERE: {
+            V3 temp;
+            hit = sphere_t(p, r, temp, t);
+            if (hit) n = ((temp + t * r.d) / p[3]) * p[4];
+        } break;
+        case RTAMD_PLANE:
+            hit = plane_t(ld3(p), ld3(p + 3), r, t);
+            n = ld3(p + 3);
+            break;
+        case RTAMD_CHECKER_PLANE:
+            hit = plane_t(ld3(p), ld3(p + 3), r, t);
+            n = ld3(p + 3);
+            if (hit) {                                        // geometry.py:353-360
+                const V3 rel = (r.o + t * r.d) - ld3(p);
+                const double x = round(dot(rel, ld3(p + 6)) / p[12]);
+                const double y = round(dot(rel, ld3(p + 9)) / p[12]);
+                if (fmod(x + y, 2.0) != 0) mat = ob.alt_material;
+            }
+            break;
+        case RTAMD_RECTANGLE:
+            hit = rectangle_t(p, r, t);
+            n = ld3(p + 3);
+            break;
+        case RTAMD_BOX:
+            hit = box_hit(p, r, t, n);
+            break;
+        case RTAMD_TRIANGLE: {
+            const double g[9] = {p[0], p[1], p[2], p[3] - p[0], p[4] - p[1], p[5] - p[2],
+                                 p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+            double a, b;
+            hit = tri_solve(g, r, a, b, t);
+            if (hit) n = ob.smooth ? ((1 - a - b) * ld3(p + 12) + a * ld3(p + 15)) + b * ld3(p + 18) : ld3(p + 9);
+        } break;
+        case RTAMD_KDTREE: {
+            const rtamd_tree& T = S.trees[ob.tree];
+            TriHit th;
+            hit = kd_closest<COUNT>(S, T, r, w, th);
+            if (hit) {
+                t = th.t;
+                prim = S.tri_prim[th.ref] & (NO_SHADOW_BIT - 1);
+                const int64_t gp = (int64_t)T.prim_offset + prim;
+                const double* nn = S.prim_normals + S.prim_normal_offset[gp];
+                n = T.smooth ? ((1 - th.alpha - th.beta) * ld3(nn) + th.alpha * ld3(nn + 3)) + th.beta * ld3(nn + 6)
+                             : ld3(nn);
+                mat = S.prim_material[gp];
+            }
+        } break;
+        default: break;
+        }
+        if (hit && t < tmin) {
+            tmin = t;
+            any = true;
+            h.t = t;
+            h.n = ob.has_transform ? normal_to_world(ob, n) : n;
+            h.material = mat;
+            h.object = i;
+            h.prim = prim;
+        }
+    }
+    if (any) h.p = ray.o + tmin * ray.d;
+    return any;
+}
+
+// obj.shadow_hit for one world object.
+template <bool COUNT>
+__device__ __forceinline__ bool shadow_hit(const rtamd_scene_desc& S, const rtamd_object& ob, const Ray& ray,
+                                           Work<COUNT>& w, double& t) {
+    const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+    const double* p = ob.p;
+    if (ob.kind == RTAMD_KDTREE) return kd_shadow<COUNT>(S, S.trees[ob.tree], r, w, t);
+    if (!ob.cast_shadow) return false;
+    w.analytic();
+    switch (ob.kind) {
+    case RTAMD_SPHERE: { V3 temp; return sphere_t(p, r, temp, t); }
+    case RTAMD_PLANE:
+    case RTAMD_CHECKER_PLANE: return plane_t(ld3(p), ld3(p + 3), r, t);
+    case RTAMD_RECTANGLE: return rectangle_t(p, r, t);
+    case RTAMD_BOX: return box_shadow(p, r, t);
+    case RTAMD_TRIANGLE: {
+        const double g[9] = {p[0], p[1], p[2], p[3] - p[0], p[4] - p[1], p[5] - p[2],
+                             p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+        double a, b;
+        return tri_solve(g, r, a, b, t);
+    }
+    default: return false;
+    }
+}
+
+// light.in_shadow: any object that reports a hit [closer than `limit`]
+// (light.py:31-37 with a distance, :60-65 / :78-83 / :170-175 without).
+template <bool COUNT>
+__device__ bool occluded(const rtamd_scene_desc& S, const Ray& ray, bool use_limit, double limit, Work<COUNT>& w) {
+    w.shadow++;
+    for (int i = 0; i < S.n_objects; ++i) {
+        double t;
+        if (shadow_hit<COUNT>(S, S.objects[i], ray, w, t) && (!use_limit || t < limit)) return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- shading
+// Local frame used by AmbientOccluder.L and EnvironmentLight.get_direction
+// (light.py:86-89, :153-156).
+__device__ __forceinline__ V3 hemisphere_about(V3 w, V3 sp) {
+    V3 v = cross(w, v3(0.0072, 1.0, 0.0034));
+    v = v / norm(v);
+    const V3 u = cross(v, w);
+    return (u * sp.x + v * sp.y) + w * sp.z;
+}
+
+// ambient_color.L(sr): AmbientLight (light.py:14-15) or AmbientOccluder (light.py:85-100).
+template <bool COUNT>
+__device__ __forceinline__ V3 ambient_radiance(const rtamd_scene_desc& S, const Hit& h, Draw& dr, Work<COUNT>& w) {
+    if (S.ambient.kind == RTAMD_AMBIENT_CONSTANT) return ld3(S.ambient.radiance);
+    Ray sr;
+    sr.o = h.p;
+    sr.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
+    return occluded<COUNT>(S, sr, false, 0.0, w) ? ld3(S.ambient.occluded) : ld3(S.ambient.radiance);
+}
+
+// GlossySpecular.f (material.py:88-97) with ks*cs folded into `spec`.
+__device__ __forceinline__ V3 phong_lobe(V3 spec, double exp_, V3 n, V3 wo, V3 wi) {
+    const double ndotwi = dot(n, wi);
+    const V3 r = (-wi) + (2.0 * n) * ndotwi;
+    const double rdotwo = dot(r, wo);
+    if (rdotwo > 0.0) return spec * pow(rdotwo, exp_);
+    return v3(0, 0, 0);
+}
+
+// The direct-lighting loop shared by Matte/Phong .shade and .area_light_shade
+// (material.py:251-281, :346-377).  `area` selects the G/pdf weighting.
+template <bool COUNT>
+__device__ V3 direct_light(const rtamd_scene_desc& S, const rtamd_material& m, const Hit& h, V3 wo,
+                           bool area, Draw& dr, Work<COUNT>& w) {
+    V3 L = ld3(m.ambient) * ambient_radiance<COUNT>(S, h, dr, w);
+    const bool phong = m.kind != RTAMD_MATTE;
+    // Matte.shade alone ignores receives_shadow (material.py:263 vs :279, :358, :374)
+    const bool gate = (phong || area) ? (m.receives_shadow != 0) : true;
+    for (int li = 0; li < S.n_lights; ++li) {
+        const rtamd_light& lt = S.lights[li];
+        V3 wi, sample_point = v3(0, 0, 0);
+        switch (lt.kind) {
+        case RTAMD_POINT: {                                  // light.py:27-29
+            const V3 v = ld3(lt.position) - h.p;
+            wi = v / norm(v);
+        } break;
+        case RTAMD_DIRECTIONAL:                              // light.py:54-55
+            wi = ld3(lt.position);
+            break;
+        case RTAMD_AREA: {                                   // light.py:116-122, geometry.py:378-380
+            double sx, sy;
+            draw_square(S, lt.sampler, dr, sx, sy);
+            sample_point = (ld3(lt.position) + sx * ld3(lt.edge_u)) + sy * ld3(lt.edge_v);
+            const V3 v = sample_point - h.p;
+            wi = v / norm(v);
+        } break;
+        default:                                             // ENVIRONMENT, light.py:152-165
+            wi = hemisphere_about(h.n, draw_hemisphere(S, lt.sampler, dr));
+            break;
+        }
+        const double ndotwi = dot(h.n, wi);
+        if (!(ndotwi > 0)) continue;
+        bool in_shadow = false;
+        if (lt.cast_shadow) {
+            Ray sr;
+            sr.o = h.p;
+            sr.d = wi;
+            if (lt.kind == RTAMD_POINT)
+                in_shadow = occluded<COUNT>(S, sr, true, norm(sr.o - ld3(lt.position)), w);      // light.py:32
+            else if (lt.kind == RTAMD_AREA)
+                in_shadow = occluded<COUNT>(S, sr, true, dot(sample_point - sr.o, sr.d), w);      // light.py:125
+            else
+                in_shadow = occluded<COUNT>(S, sr, false, 0.0, w);
+        }
+        if (in_shadow || !gate) continue;
+        V3 f = ld3(m.diffuse);
+        if (phong) f = f + phong_lobe(ld3(m.specular), m.exp, h.n, wo, wi);
+        V3 Ll = ld3(lt.radiance);
+        if (lt.kind == RTAMD_POINT && lt.attenuation != 0)                                        // light.py:39-44
+            Ll = Ll * pow(norm(h.p - ld3(lt.position)) / lt.radius, -lt.attenuation);
+        if (lt.kind == RTAMD_AREA && !(dot(ld3(lt.normal), wi) < 0.)) Ll = v3(0, 0, 0);            // light.py:110-114
+        V3 term = (f * Ll) * ndotwi;
+        if (area) {
+            double G = 1.0, pdf = 1.0;                                                            // light.py:149-150, :177-178
+            if (lt.kind == RTAMD_AREA) {                                                          // light.py:132-140
+                const double ndotd = -dot(ld3(lt.normal), wi);
+                const V3 dv = sample_point - h.p;
+                const double d2 = (((0 + dv.x * dv.x) + dv.y * dv.y) + dv.z * dv.z) / (lt.radius * lt.radius);
+                G = ndotd / pymax(1., d2);
+                pdf = lt.pdf;
+            }
+            term = (term * G) / pdf;
+        }
+        L = L + term;
+    }
+    return L;
+}
+
+struct Primary { int32_t object, prim; double t; };
+
+// tracer.trace_ray (tracer.py:26-35, :65-71, :79-88) with the single-child recursion of
+// Reflective / GlossyReflective / Matte.path_shade (material.py:385-411, :283-289)
+// unrolled into a loop: radiance = sum over bounces of (product of child weights) * local.
+template <bool COUNT>
+__device__ V3 trace(const rtamd_scene_desc& S, Ray ray, int depth, Draw& dr, Work<COUNT>& w, Primary& first) {
+    V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
+    const V3 background = (S.tracer_kind == RTAMD_TRACER_SHADE) ? ld3(S.background) : v3(0, 0, 0);
+    first.object = -1; first.prim = -1; first.t = 0;
+    bool primary = true;
+    for (;; ++depth) {
+        if (S.tracer_kind != RTAMD_TRACER_AREA && depth > S.depth_limit) { L = L + W * background; break; }
+        Hit h;
+        if (!closest_hit<COUNT>(S, ray, w, h)) { L = L + W * background; break; }
+        if (primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; primary = false; }
+        const rtamd_material& m = S.materials[h.material];
+        const V3 wo = -ray.d;
+
+        if (m.kind == RTAMD_EMISSIVE) {
+            V3 e;
+            if (S.tracer_kind == RTAMD_TRACER_SHADE) e = v3(1., 1., 1.);                           // material.py:495-496
+            else if (S.tracer_kind == RTAMD_TRACER_AREA)
+                e = (-dot(h.n, ray.d) > 0) ? ld3(m.emit) : v3(0, 0, 0);                             // material.py:498-502
+            else e = (dot(h.n, ray.d) < 0) ? ld3(m.emit) : v3(0, 0, 0);                             // material.py:504-508
+            L = L + W * e;
+            break;
+        }
+
+        if (S.tracer_kind == RTAMD_TRACER_PATH) {
+            // Lambertian.sample_f (material.py:41-53) then Matte.path_shade (:283-289)
+            V3 v = cross(v3(0.0034, 1, 0.0071), h.n);
+            v = v / norm(v);
+            const V3 u = cross(v, h.n);
+            const V3 sp = draw_hemisphere(S, m.sampler, dr);
+            V3 wi = (sp.x * u + sp.y * v) + sp.z * h.n;
+            wi = wi / norm(wi);
+            const double pdf = dot(h.n, wi) / PI;
+            const double ndotwi = dot(h.n, wi);
+            W = W * ((ld3(m.diffuse) * ndotwi) / pdf);
+            ray.o = h.p;
+            ray.d = wi;
+            continue;
+        }
+
+        const bool area = S.tracer_kind == RTAMD_TRACER_AREA;
+        L = L + W * direct_light<COUNT>(S, m, h, wo, area, dr, w);
+        if (area) break;
+
+        if (m.kind == RTAMD_REFLECTIVE) {
+            // PerfectSpecular.sample_f (material.py:69-74), Reflective.shade (:385-394)
+            const double ndotwo = dot(h.n, wo);
+            const V3 wi = (-wo) + (2.0 * h.n) * ndotwo;
+            const double pdf = dot(h.n, wi);
+            const V3 fr = ld3(m.reflect) / pdf;
+            W = W * (fr * dot(h.n, wi));
+            ray.o = h.p;
+            ray.d = wi;
+        } else if (m.kind == RTAMD_GLOSSY_REFLECTIVE) {
+            // GlossySpecular.sample_f (material.py:102-121), GlossyReflective.shade (:402-411)
+            const double ndotwo = dot(h.n, wo);
+            const V3 wr = (-wo) + (2.0 * h.n) * ndotwo;
+            V3 u = cross(v3(0.00424, 1., 0.00767), wr);
+            u = u / norm(u);
+            const V3 v = cross(u, wr);
+            const V3 sp = draw_hemisphere(S, m.sampler, dr);
+            V3 wi = (sp.x * u + sp.y * v) + sp.z * wr;
+            if (dot(h.n, wi) < 0.0) wi = ((-sp.x) * u - sp.y * v) + sp.z * wr;
+            const double lobe = pow(dot(wr, wi), m.reflect_exp);
+            double pdf = lobe * dot(h.n, wi);
+            V3 fr;
+            if (pdf == 0) { fr = v3(0, 0, 0); pdf = 1; }
+            else fr = ld3(m.reflect) * lobe;
+            W = W * ((fr * dot(h.n, wi)) / pdf);
+            ray.o = h.p;
+            ray.d = wi;
+        } else {
+            break;
+        }
+    }
+    return L;
+}
+
+// int(c*255) as camera.py:66 does it: truncation toward zero.  Python raises on NaN or
+// infinity; those become 0 / the int32 limits here.
+__device__ __forceinline__ int32_t quantise(double c) {
+    const double s = c * 255;
+    if (!(s == s)) return 0;
+    if (s >= 2147483647.0) return 2147483647;
+    if (s <= -2147483648.0) return (int32_t)0x80000000;
+    return (int32_t)s;
+}
+
+}  // namespace rt

@@ -1,0 +1,320 @@
+// Kernels and the C ABI of include/raytracer_amd.h.
+//
+// One lane traces one sample; a wave of the tile kernel holds the 64 pixels of one
+// 8x8-pixel tile at one sample index, so primary rays of a wave stay close together.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "rt_device.h"
+
+using namespace rt;
+
+namespace {
+
+enum { MODE_PIXELS = 0, MODE_RAYS = 1, MODE_TILES = 2 };
+constexpr int BLOCK = 256;
+
+struct LaunchArgs {
+    rtamd_camera cam;
+    uint64_t trace_key, pixel_key;
+    int64_t n;
+    const int32_t* pixel_index;
+    const int32_t* sample_index;
+    const double* a3;           // plane points / origins
+    const double* b3;           // lens points / directions
+    const int32_t* tile_ids;
+    int32_t depth0;
+    int32_t sample_begin, n_samples, tiles_x;
+    rtamd_sample_out out;
+    int64_t* sum_rgb8;
+    double* sum_sq;
+    unsigned long long* counters;
+};
+
+// PinholeCamera.ray_direction (camera.py:31-33) / ThinLensCamera.ray_direction (:222-225)
+__device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point, V3 lens_point) {
+    Ray r;
+    const V3 u = ld3(c.u), v = ld3(c.v), w = ld3(c.w);
+    if (c.thin_lens) {
+        const V3 f = (plane_point * c.focal_plane_distance) / c.viewing_distance;
+        const V3 d = ((f.x - lens_point.x) * u + (f.y - lens_point.y) * v) - c.focal_plane_distance * w;
+        r.o = lens_point;
+        r.d = d / norm(d);
+    } else {
+        const V3 d = (plane_point.x * u + plane_point.y * v) - c.viewing_distance * w;
+        r.o = ld3(c.eye);
+        r.d = d / norm(d);
+    }
+    return r;
+}
+
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
+    const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool live = k < A.n;
+    Work<COUNT> work;
+    int64_t acc_row = -1;
+
+    if (live) {
+        Ray ray;
+        int32_t pixel = 0, sample = 0;
+        if (MODE == MODE_RAYS) {
+            pixel = A.pixel_index ? A.pixel_index[k] : 0;
+            sample = A.sample_index ? A.sample_index[k] : 0;
+            ray.o = ld3(A.a3 + 3 * k);
+            ray.d = ld3(A.b3 + 3 * k);
+        } else if (MODE == MODE_PIXELS) {
+            pixel = A.pixel_index[k];
+            sample = A.sample_index[k];
+            const V3 lens = A.cam.thin_lens ? ld3(A.b3 + 3 * k) : v3(0, 0, 0);
+            ray = camera_ray(A.cam, ld3(A.a3 + 3 * k), lens);
+        } else {
+            // sample k = (tile position, sample offset, pixel in tile)
+            const int32_t pix = (int32_t)(k & 63);
+            const int64_t q = k >> 6;
+            const int32_t soff = (int32_t)(q % A.n_samples);
+            const int64_t tpos = q / A.n_samples;
+            const int32_t tile = A.tile_ids[tpos];
+            const int32_t col = (tile % A.tiles_x) * 8 + (pix & 7);
+            const int32_t row = (tile / A.tiles_x) * 8 + (pix >> 3);
+            if (col >= A.cam.width || row >= A.cam.height) {
+                live = false;
+            } else {
+                pixel = row * A.cam.width + col;
+                sample = A.sample_begin + soff;
+                acc_row = tpos * 64 + pix;
+                // camera.py:78 (+ :246): one pattern choice per pixel, plus an independent
+                // disk pattern for a thin lens; camera.py:90-93: the view-plane point.
+                const rtamd_sampler sm = S.samplers[A.cam.sampler];
+                Draw pd;
+                pd.key = mix64(A.pixel_key ^ (uint64_t)(uint32_t)pixel);
+                pd.sample = 0;
+                pd.counter = 0;
+                const uint32_t pat = sm.regular ? 0u : pd.index((uint32_t)sm.num_patterns);
+                const double* sq = S.sampler_data + sm.square_offset + 2 * ((int64_t)pat * sm.samples_per_pattern + sample);
+                const V3 pp = v3(A.cam.pixel_size * (col - A.cam.width / 2 + sq[0]),
+                                 A.cam.pixel_size * (row - A.cam.height / 2 + sq[1]), 0.0);
+                V3 lens = v3(0, 0, 0);
+                if (A.cam.thin_lens) {
+                    const uint32_t dpat = sm.regular ? 0u : pd.index((uint32_t)sm.num_patterns);
+                    const double* dk = S.sampler_data + sm.disk_offset + 2 * ((int64_t)dpat * sm.samples_per_pattern + sample);
+                    lens = ld3(A.cam.eye) + v3(dk[0], dk[1], 0.0) * A.cam.lens_radius;   // camera.py:262
+                }
+                ray = camera_ray(A.cam, pp, lens);
+            }
+        }
+
+        if (live) {
+            Draw dr;
+            dr.key = mix64(A.trace_key ^ (uint64_t)(uint32_t)pixel);
+            dr.sample = (uint32_t)sample;
+            dr.counter = 0;
+            Primary first;
+            const V3 c = trace<COUNT>(S, ray, A.depth0, dr, work, first);
+
+            const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
+            if (A.out.rgb) { A.out.rgb[3 * k] = c.x; A.out.rgb[3 * k + 1] = c.y; A.out.rgb[3 * k + 2] = c.z; }
+            if (A.out.rgb8) { A.out.rgb8[3 * k] = r8; A.out.rgb8[3 * k + 1] = g8; A.out.rgb8[3 * k + 2] = b8; }
+            if (A.out.hit_object) A.out.hit_object[k] = first.object;
+            if (A.out.hit_prim) A.out.hit_prim[k] = first.prim;
+            if (A.out.hit_t) A.out.hit_t[k] = first.t;
+            if (A.out.n_rays) { A.out.n_rays[2 * k] = (int32_t)work.closest; A.out.n_rays[2 * k + 1] = (int32_t)work.shadow; }
+            if (MODE == MODE_TILES) {
+                if (A.sum_rgb8) {
+                    unsigned long long* s = reinterpret_cast<unsigned long long*>(A.sum_rgb8) + 3 * acc_row;
+                    atomicAdd(s, (unsigned long long)(long long)r8);
+                    atomicAdd(s + 1, (unsigned long long)(long long)g8);
+                    atomicAdd(s + 2, (unsigned long long)(long long)b8);
+                }
+                if (A.sum_sq) {
+                    double* s = A.sum_sq + 3 * acc_row;
+                    atomicAdd(s, c.x * c.x);
+                    atomicAdd(s + 1, c.y * c.y);
+                    atomicAdd(s + 2, c.z * c.z);
+                }
+            }
+        }
+    }
+
+    if (A.counters) {
+        // one add per counter per block
+        __shared__ unsigned int blk[RTAMD_N_COUNTERS];
+        if (threadIdx.x < RTAMD_N_COUNTERS) blk[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned int vals[7] = {work.closest, work.shadow, live ? 1u : 0u, work.nodes(),
+                                      work.leaves(), work.tris(), work.analytics()};
+        for (int i = 0; i < 7; ++i) {
+            unsigned int v = vals[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&blk[i], v);
+        }
+        __syncthreads();
+        if (threadIdx.x < 7 && blk[threadIdx.x]) atomicAdd(&A.counters[threadIdx.x], (unsigned long long)blk[threadIdx.x]);
+    }
+}
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char* fmt, const char* detail = "") {
+    snprintf(g_error, sizeof(g_error), fmt, detail);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_error, sizeof(g_error), "%s: %s", what, hipGetErrorString(e));
+    return RTAMD_EHIP;
+}
+
+template <int MODE>
+int launch(const rtamd_scene_desc& S, const LaunchArgs& A, uint32_t flags, void* stream) {
+    if (A.n <= 0) return RTAMD_OK;
+    const int64_t blocks = (A.n + BLOCK - 1) / BLOCK;
+    if (blocks > 0x7fffffffLL) return fail(RTAMD_EINVAL, "too many samples for one launch%s");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & RTAMD_COUNT_WORK)
+        hipLaunchKernelGGL((trace_kernel<MODE, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, S, A);
+    else
+        hipLaunchKernelGGL((trace_kernel<MODE, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, S, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return RTAMD_OK;
+}
+
+}  // namespace
+
+struct rtamd_scene {
+    rtamd_scene_desc desc;
+    int device;
+};
+
+extern "C" {
+
+int rtamd_abi_version(void) { return RTAMD_ABI_VERSION; }
+
+const char* rtamd_last_error(void) { return g_error; }
+
+int rtamd_device_check(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(RTAMD_ENODEVICE, "no HIP device is available%s");
+    return RTAMD_OK;
+}
+
+int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
+    if (!d || !out) return fail(RTAMD_EINVAL, "null argument%s");
+    if (d->abi_version != RTAMD_ABI_VERSION) return fail(RTAMD_EINVAL, "descriptor ABI version mismatch%s");
+    if (d->tracer_kind < RTAMD_TRACER_SHADE || d->tracer_kind > RTAMD_TRACER_PATH)
+        return fail(RTAMD_EUNSUPPORTED, "unknown tracer kind%s");
+    if (d->n_objects < 0 || d->n_materials < 0 || d->n_lights < 0 || d->n_samplers < 1 || d->n_trees < 0)
+        return fail(RTAMD_EINVAL, "negative table size, or no view-plane sampler%s");
+    if ((d->n_objects && !d->objects) || (d->n_materials && !d->materials) || (d->n_lights && !d->lights) ||
+        !d->samplers || !d->sampler_data)
+        return fail(RTAMD_EINVAL, "a non-empty table has a null pointer%s");
+    if (d->n_trees && (!d->trees || !d->kd_nodes || !d->tri_geom || !d->tri_prim || !d->prim_normals ||
+                       !d->prim_normal_offset || !d->prim_material))
+        return fail(RTAMD_EINVAL, "kd-tree tables missing%s");
+    if (d->ambient.kind != RTAMD_AMBIENT_CONSTANT && d->ambient.kind != RTAMD_AMBIENT_OCCLUDER)
+        return fail(RTAMD_EUNSUPPORTED, "unknown ambient kind%s");
+    if (d->ambient.kind == RTAMD_AMBIENT_OCCLUDER && (d->ambient.sampler < 0 || d->ambient.sampler >= d->n_samplers))
+        return fail(RTAMD_EINVAL, "ambient occluder sampler out of range%s");
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    rtamd_scene* s = new (std::nothrow) rtamd_scene;
+    if (!s) return fail(RTAMD_EINVAL, "out of host memory%s");
+    s->desc = *d;
+    s->device = dev;
+    *out = s;
+    return RTAMD_OK;
+}
+
+int rtamd_scene_destroy(rtamd_scene* scene) {
+    delete scene;
+    return RTAMD_OK;
+}
+
+static int check_camera(const rtamd_scene* scene, const rtamd_camera* c) {
+    if (!scene || !c) return fail(RTAMD_EINVAL, "null scene or camera%s");
+    if (c->width <= 0 || c->height <= 0) return fail(RTAMD_EINVAL, "empty view plane%s");
+    if (c->sampler < 0 || c->sampler >= scene->desc.n_samplers) return fail(RTAMD_EINVAL, "camera sampler out of range%s");
+    return RTAMD_OK;
+}
+
+int rtamd_render_pixels(rtamd_scene* scene, const rtamd_camera* camera, uint64_t seed, int64_t n,
+                        const int32_t* pixel_index, const int32_t* sample_index, const double* plane_points,
+                        const double* lens_points, const rtamd_sample_out* out, uint64_t* counters,
+                        uint32_t flags, void* stream) {
+    int rc = check_camera(scene, camera);
+    if (rc) return rc;
+    if (n < 0) return fail(RTAMD_EINVAL, "negative sample count%s");
+    if (n == 0) return RTAMD_OK;
+    if (!pixel_index || !sample_index || !plane_points || !out) return fail(RTAMD_EINVAL, "null sample buffer%s");
+    if (camera->thin_lens && !lens_points) return fail(RTAMD_EINVAL, "a thin-lens camera needs lens points%s");
+    LaunchArgs A;
+    memset(&A, 0, sizeof(A));
+    A.cam = *camera;
+    A.trace_key = phase_key(seed, PHASE_TRACE);
+    A.pixel_key = phase_key(seed, PHASE_PIXEL);
+    A.n = n;
+    A.pixel_index = pixel_index;
+    A.sample_index = sample_index;
+    A.a3 = plane_points;
+    A.b3 = lens_points;
+    A.out = *out;
+    A.counters = reinterpret_cast<unsigned long long*>(counters);
+    return launch<MODE_PIXELS>(scene->desc, A, flags, stream);
+}
+
+int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t* pixel_index,
+                     const int32_t* sample_index, const double* origins, const double* directions,
+                     int32_t depth, const rtamd_sample_out* out, uint64_t* counters, uint32_t flags,
+                     void* stream) {
+    if (!scene) return fail(RTAMD_EINVAL, "null scene%s");
+    if (n < 0) return fail(RTAMD_EINVAL, "negative ray count%s");
+    if (n == 0) return RTAMD_OK;
+    if (!origins || !directions || !out) return fail(RTAMD_EINVAL, "null ray buffer%s");
+    LaunchArgs A;
+    memset(&A, 0, sizeof(A));
+    A.trace_key = phase_key(seed, PHASE_TRACE);
+    A.pixel_key = phase_key(seed, PHASE_PIXEL);
+    A.n = n;
+    A.pixel_index = pixel_index;
+    A.sample_index = sample_index;
+    A.a3 = origins;
+    A.b3 = directions;
+    A.depth0 = depth;
+    A.out = *out;
+    A.counters = reinterpret_cast<unsigned long long*>(counters);
+    return launch<MODE_RAYS>(scene->desc, A, flags, stream);
+}
+
+int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t seed, int64_t n_tiles,
+                       const int32_t* tile_ids, int32_t sample_begin, int32_t sample_end,
+                       const rtamd_sample_out* per_sample, int64_t* sum_rgb8, double* sum_sq,
+                       uint64_t* counters, uint32_t flags, void* stream) {
+    int rc = check_camera(scene, camera);
+    if (rc) return rc;
+    if (n_tiles < 0 || sample_begin < 0 || sample_end < sample_begin) return fail(RTAMD_EINVAL, "bad tile or sample range%s");
+    if (n_tiles == 0 || sample_end == sample_begin) return RTAMD_OK;
+    if (!tile_ids) return fail(RTAMD_EINVAL, "null tile list%s");
+    LaunchArgs A;
+    memset(&A, 0, sizeof(A));
+    A.cam = *camera;
+    A.trace_key = phase_key(seed, PHASE_TRACE);
+    A.pixel_key = phase_key(seed, PHASE_PIXEL);
+    A.n_samples = sample_end - sample_begin;
+    A.sample_begin = sample_begin;
+    A.n = n_tiles * 64 * (int64_t)A.n_samples;
+    A.tile_ids = tile_ids;
+    A.tiles_x = (camera->width + 7) / 8;
+    if (per_sample) A.out = *per_sample;
+    A.sum_rgb8 = sum_rgb8;
+    A.sum_sq = sum_sq;
+    A.counters = reinterpret_cast<unsigned long long*>(counters);
+    return launch<MODE_TILES>(scene->desc, A, flags, stream);
+}
+
+}  // extern "C"
