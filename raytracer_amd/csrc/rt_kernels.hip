@@ -188,6 +188,8 @@ int launch(const rtamd_scene_desc& S, const LaunchArgs& A, uint32_t flags, void*
 struct rtamd_scene {
     rtamd_scene_desc desc;
     int device;
+    rtamd_sampler* samplers_host;   // host copies of the small tables, for argument checks
+    int max_tree_depth;
 };
 
 extern "C" {
@@ -202,6 +204,8 @@ int rtamd_device_check(void) {
     if (e != hipSuccess || n == 0) return fail(RTAMD_ENODEVICE, "no HIP device is available%s");
     return RTAMD_OK;
 }
+
+int rtamd_scene_destroy(rtamd_scene* scene);
 
 int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
     if (!d || !out) return fail(RTAMD_EINVAL, "null argument%s");
@@ -227,11 +231,35 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
     if (!s) return fail(RTAMD_EINVAL, "out of host memory%s");
     s->desc = *d;
     s->device = dev;
+    s->max_tree_depth = 0;
+    s->samplers_host = new (std::nothrow) rtamd_sampler[d->n_samplers];
+    if (!s->samplers_host) { delete s; return fail(RTAMD_EINVAL, "out of host memory%s"); }
+    e = hipMemcpy(s->samplers_host, d->samplers, sizeof(rtamd_sampler) * d->n_samplers, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the sampler table"); }
+    for (int i = 0; i < d->n_samplers; ++i) {
+        const rtamd_sampler& sm = s->samplers_host[i];
+        const int64_t n = (int64_t)sm.num_patterns * sm.samples_per_pattern;
+        if (sm.num_patterns < 1 || sm.samples_per_pattern < 1 || sm.square_offset < 0 || sm.disk_offset < 0 ||
+            sm.hemi_offset < 0 || sm.square_offset + 2 * n > d->n_sampler_doubles ||
+            sm.disk_offset + 2 * n > d->n_sampler_doubles || sm.hemi_offset + 3 * n > d->n_sampler_doubles) {
+            rtamd_scene_destroy(s);
+            return fail(RTAMD_EINVAL, "a sampler table lies outside sampler_data%s");
+        }
+    }
+    for (int i = 0; i < d->n_trees; ++i) {
+        rtamd_tree t;
+        e = hipMemcpy(&t, d->trees + i, sizeof(t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the tree table"); }
+        if (t.depth + 2 > STACK_MAX) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "kd-tree deeper than the traversal stack%s"); }
+        if (t.node_offset < 0 || t.node_offset >= d->n_kd_nodes) { rtamd_scene_destroy(s); return fail(RTAMD_EINVAL, "tree root outside kd_nodes%s"); }
+        if (t.depth > s->max_tree_depth) s->max_tree_depth = t.depth;
+    }
     *out = s;
     return RTAMD_OK;
 }
 
 int rtamd_scene_destroy(rtamd_scene* scene) {
+    if (scene) delete[] scene->samplers_host;
     delete scene;
     return RTAMD_OK;
 }
@@ -300,6 +328,8 @@ int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t 
     if (n_tiles < 0 || sample_begin < 0 || sample_end < sample_begin) return fail(RTAMD_EINVAL, "bad tile or sample range%s");
     if (n_tiles == 0 || sample_end == sample_begin) return RTAMD_OK;
     if (!tile_ids) return fail(RTAMD_EINVAL, "null tile list%s");
+    if (sample_end > scene->samplers_host[camera->sampler].samples_per_pattern)
+        return fail(RTAMD_EINVAL, "sample range exceeds the view-plane sampler's pattern size%s");
     LaunchArgs A;
     memset(&A, 0, sizeof(A));
     A.cam = *camera;
