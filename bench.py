@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s on the dragon kd-tree scene (1920x1080, 16 samples per
+pixel, ambient occlusion + area-light soft shadows), whole job over N GPUs of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one full frame: every rank traces its share of the 8x8-pixel tiles (all 16
+samples of each pixel) and the tile-compact accumulators are gathered on rank 0 (RCCL).
+The frame is fixed, so scaling is "strong".  A ray is one closest-hit query or one
+shadow/occlusion query, counted in the kernel.  Rank 0 prints ONE JSON line.
+
+Extra fields:
+  roofline      algorithmic bytes per launch / measured kernel time against the HBM peak.
+                Algorithmic bytes follow the per-ray accounting 48 B (ray + hit record)
+                + 16 B per kd interior step + 72 B per triangle test (v0, e1, e2 in f64)
+                + 48 B per analytic object test, with the step/test counts of the
+                reference algorithm taken from a counting launch of the same frame.
+  cpu_baseline  the CPU checker (oracle/, a float64 port of the same path) timed on this
+                host over a bounded sample of the same workload, OpenMP threads stated.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+
+WORKLOADS = {
+    # name -> (scene, overrides)
+    "dragon_1080p_16spp_ao_arealight": ("dragon_area", dict(resolution=(1920, 1080), sample_dim=4)),
+    "dragon_480x270_16spp_ao_arealight": ("dragon_area", dict(resolution=(480, 270), sample_dim=4)),
+    "cornellbox_200_16spp_arealight": ("cornellbox_area", None),
+}
+
+
+def algorithmic_bytes(c):
+    rays = c["closest"] + c["shadow"]
+    return 48 * rays + 16 * c["kd_nodes"] + 72 * c["tri_tests"] + 48 * c["analytic_tests"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="dragon_1080p_16spp_ao_arealight", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    import numpy
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world_size, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                device_id=torch.device("cuda", local_rank))
+
+    from raytracer_amd.world import World
+    from raytracer_amd import distributed, flatten, runtime
+
+    scene, overrides = WORKLOADS[args.workload]
+    world = World.__new__(World)
+    if overrides:
+        world.overrides = overrides
+    t_build = time.time()
+    World.__init__(world, viewmode="parallel", buildfunction=scene, seed=args.seed)
+    ds = runtime.device_scene(world)
+    t_build = time.time() - t_build
+    cam = flatten.camera_record(world)
+    job = distributed.FrameJob(world, rank, world_size)
+    n_samples = job.n_samples
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        parts = job.render()
+        return parts
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ds.read_counters(reset=True)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        # events bracket the tile kernel on the stream it is launched on (torch's current stream)
+        job.sum_rgb8.zero_()
+        ev0[i].record()
+        job.render_fn(job.tile_ids, job.sum_rgb8, None)
+        ev1[i].record()
+        parts = distributed.gather_to_root(job.sum_rgb8)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    counters = ds.read_counters(reset=True)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+
+    # whole-job numbers: max time over ranks, sum of rays over ranks
+    stats = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([counters["closest"] + counters["shadow"], counters["samples"]], dtype=torch.int64, device="cuda")
+    if world_size > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed, kernel_ms = float(stats[0]), float(stats[1])
+    total_rays, total_samples = int(rays[0]), int(rays[1])
+    rays_per_frame = total_rays / float(args.steps)
+
+    # roofline of the dominant (only) kernel on rank 0: one counting launch of this rank's share
+    ds.read_counters(reset=True)
+    job.sum_rgb8.zero_()
+    ds.render_tiles(cam, world.seed, job.tile_ids, 0, n_samples, sum_rgb8=job.sum_rgb8, count_work=True)
+    torch.cuda.synchronize()
+    work = ds.read_counters(reset=True)
+    algo_bytes = algorithmic_bytes(work)
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+
+    traffic = None
+    traffic_file = os.path.join(REPO, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(traffic_file):
+        with open(traffic_file) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+
+    cpu = None
+    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(world, ds, cam, n_samples, args.cpu_seconds)
+
+    if world_size > 1:
+        dist.barrier()
+    if rank == 0:
+        frame = job.finish(parts)
+        line = {
+            "metric": "Mrays/s (whole node) on dragon.obj kd-tree scene",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "scene": scene, "resolution": list(world.viewplane.resolution),
+                       "samples_per_pixel": n_samples, "rays_per_frame": rays_per_frame,
+                       "samples_per_frame": total_samples / float(args.steps),
+                       "tiles": "8x8 px, diagonal interleave over ranks, RCCL gather to rank 0",
+                       "scene_bytes": ds.flat.nbytes(), "host_scene_build_s": round(t_build, 2),
+                       "frame_mean_rgb": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "trace_kernel<tiles>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_bytes_per_ray": algo_bytes / float(max(work["closest"] + work["shadow"], 1)),
+                         "work_per_ray": {k: work[k] / float(max(work["closest"] + work["shadow"], 1))
+                                          for k in ("kd_nodes", "kd_leaves", "tri_tests", "analytic_tests")}},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(world, ds, cam, n_samples, target_seconds):
+    """Time the CPU checker on randomly chosen whole tiles of the same frame."""
+    import numpy
+    from oracle import oracle
+    from raytracer_amd import runtime
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    osc = oracle.OracleScene(ds.flat)
+    tx, ty = runtime.tile_grid(cam.width, cam.height)
+    order = numpy.random.RandomState(11).permutation(tx * ty).astype(numpy.int32)
+    # calibrate on a few tiles, then size the sample for about target_seconds
+    probe = order[:4 * threads]
+    t0 = time.perf_counter()
+    osc.render_tiles(cam, world.seed, probe, 0, n_samples, threads=threads)
+    dt = time.perf_counter() - t0
+    osc.read_counters(reset=True)
+    n_tiles = int(max(len(probe), min(len(order) - len(probe), len(probe) * target_seconds / max(dt, 1e-6))))
+    tiles = order[len(probe):len(probe) + n_tiles]
+    t0 = time.perf_counter()
+    osc.render_tiles(cam, world.seed, tiles, 0, n_samples, threads=threads)
+    dt = time.perf_counter() - t0
+    c = osc.read_counters(reset=True)
+    rays = c["closest"] + c["shadow"]
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "%d random 8x8 tiles x %d spp = %d samples, %d rays, %.1f s"
+                      % (len(tiles), n_samples, c["samples"], rays, dt)}
+
+
+if __name__ == "__main__":
+    main()
