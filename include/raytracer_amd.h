@@ -167,7 +167,9 @@ typedef struct rtamd_tree {
 /* Everything a render needs that does not change between frames.
  * Leaf-ordered triangle tables have one row per leaf reference (a triangle that
  * straddles a split plane appears once per leaf that holds it, kdtree.py:52):
- *   tri_geom[ref][9]  = v0, v1-v0, v2-v0
+ *   tri_geom[9][n_refs] = v0.xyz, (v1-v0).xyz, (v2-v0).xyz as nine arrays of n_refs doubles
+ *                       (component c of reference r is tri_geom[c*n_refs + r]), so the 64
+ *                       lanes of a wave load 64 consecutive references with 9 coalesced reads
  *   tri_prim[ref]     = primitive index within its tree; bit 30 set if the triangle
  *                       does not cast shadows (geometry.py:433-434)
  * Per-primitive tables (one row per triangle, all trees concatenated):

@@ -128,11 +128,16 @@ static int solve3(vec c0, vec c1, vec c2, vec rhs, double x[3]) {
     return 1;
 }
 
-/* Triangle.hit / shadow_hit acceptance (geometry.py:435-442, :448-455); g = v0, v1-v0, v2-v0 */
-static int tri_test(const double *g, const ray_t *r, double *alpha, double *beta, double *t) {
+/* Triangle.hit / shadow_hit acceptance (geometry.py:435-442, :448-455); g = v0, v1-v0, v2-v0
+ * with the nine components `stride` doubles apart (1 for a packed triangle, n_refs for a row
+ * of the scene's struct-of-arrays table) */
+static int tri_test(const double *g, int64_t stride, const ray_t *r, double *alpha, double *beta, double *t) {
     double x[3];
-    vec f = sub(P3(g), r->o);
-    if (!solve3(P3(g + 3), P3(g + 6), neg(r->d), neg(f), x)) return 0;
+    vec v0 = V(g[0], g[stride], g[2 * stride]);
+    vec d = V(g[3 * stride], g[4 * stride], g[5 * stride]);
+    vec e = V(g[6 * stride], g[7 * stride], g[8 * stride]);
+    vec f = sub(v0, r->o);
+    if (!solve3(d, e, neg(r->d), neg(f), x)) return 0;
     *alpha = x[0]; *beta = x[1]; *t = x[2];
     return x[0] > EPS && x[1] > EPS && x[2] > EPS && x[0] + x[1] < 1;
 }
@@ -337,7 +342,7 @@ static int object_hit(ctx_t *c, int idx, const ray_t *world_ray, hit_t *h) {
         double g[9], a, b;
         bare_triangle(p, g);
         c->w.tris++;
-        hit = tri_test(g, r, &a, &b, &t);
+        hit = tri_test(g, 1, r, &a, &b, &t);
         if (hit) {
             if (ob->smooth) n = add(add(scl(P3(p + 12), 1 - a - b), scl(P3(p + 15), a)), scl(P3(p + 18), b));
             else n = P3(p + 9);
@@ -353,7 +358,7 @@ static int object_hit(ctx_t *c, int idx, const ray_t *world_ray, hit_t *h) {
             for (i = 0; i < count; ++i) {
                 double a, b, tt;
                 c->w.tris++;
-                if (tri_test(S->tri_geom + 9 * (int64_t)(first + i), r, &a, &b, &tt)) {
+                if (tri_test(S->tri_geom + (int64_t)(first + i), S->n_refs, r, &a, &b, &tt)) {
                     if (best_ref < 0 || best_t > tt) { best_t = tt; best_a = a; best_b = b; best_ref = first + i; }
                 }
             }
@@ -401,7 +406,7 @@ static int object_shadow(ctx_t *c, int idx, const ray_t *world_ray, double *t) {
                 double a, b;
                 if (S->tri_prim[first + i] & NO_SHADOW_BIT) continue;     /* geometry.py:433-434 */
                 c->w.tris++;
-                if (tri_test(S->tri_geom + 9 * (int64_t)(first + i), r, &a, &b, t)) return 1;
+                if (tri_test(S->tri_geom + (int64_t)(first + i), S->n_refs, r, &a, &b, t)) return 1;
             }
         }
         return 0;
@@ -418,7 +423,7 @@ static int object_shadow(ctx_t *c, int idx, const ray_t *world_ray, double *t) {
         double g[9], a, b;
         bare_triangle(p, g);
         c->w.tris++;
-        return tri_test(g, r, &a, &b, t);
+        return tri_test(g, 1, r, &a, &b, t);
     }
     default: return 0;
     }

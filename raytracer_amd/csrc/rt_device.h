@@ -116,14 +116,30 @@ template <> struct Work<true> {
     __device__ __forceinline__ uint32_t analytics() const { return n_analytic; }
 };
 
+// ---------------------------------------------------------------- wave helpers
+// A wave traces 64 samples in lock step.  Per-lane work (kd descent, analytic
+// primitives, shading arithmetic) runs under the usual exec mask; the triangle lists of
+// big kd leaves are tested by the whole wave for one ray at a time, so the functions
+// below are entered by all 64 lanes together and take a per-lane `active` flag instead
+// of being called from divergent code.
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ double bcast_d(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int first_lane(unsigned long long mask) {
+    return __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mask));
+}
+
 // ---------------------------------------------------------------- triangles
 // geometry.py:447-455 solves [v1-v0, v2-v0, -d] (alpha, beta, t)^T = o - v0 with LAPACK.
 // Here the same system is solved by Cramer's rule in the Moeller-Trumbore arrangement;
 // a singular system (the reference raises) is a miss because every comparison with
 // the resulting inf/NaN is false.
-__device__ __forceinline__ bool tri_solve(const double* __restrict__ g, const Ray& r,
-                                          double& alpha, double& beta, double& t) {
-    const V3 v0 = ld3(g), e1 = ld3(g + 3), e2 = ld3(g + 6);
+__device__ __forceinline__ bool tri_solve_v(V3 v0, V3 e1, V3 e2, const Ray& r,
+                                            double& alpha, double& beta, double& t) {
     const V3 pvec = cross(r.d, e2);
     const double det = dot(e1, pvec);
     const double inv = 1.0 / det;
@@ -134,9 +150,24 @@ __device__ __forceinline__ bool tri_solve(const double* __restrict__ g, const Ra
     t = dot(e2, qvec) * inv;
     return alpha > EPS && beta > EPS && t > EPS && alpha + beta < 1.0;
 }
+// bare triangle given as 9 contiguous doubles v0, e1, e2
+__device__ __forceinline__ bool tri_solve(const double* g, const Ray& r, double& alpha, double& beta, double& t) {
+    return tri_solve_v(ld3(g), ld3(g + 3), ld3(g + 6), r, alpha, beta, t);
+}
+// leaf reference `ref` of the scene's struct-of-arrays triangle table: component c of
+// row `ref` is tri_geom[c*n_refs + ref], so 64 consecutive references are 9 coalesced loads
+__device__ __forceinline__ bool tri_solve_ref(const double* __restrict__ g, int64_t n, int64_t ref, const Ray& r,
+                                              double& alpha, double& beta, double& t) {
+    const double* p = g + ref;
+    const V3 v0 = v3(p[0], p[n], p[2 * n]);
+    const V3 e1 = v3(p[3 * n], p[4 * n], p[5 * n]);
+    const V3 e2 = v3(p[6 * n], p[7 * n], p[8 * n]);
+    return tri_solve_v(v0, e1, e2, r, alpha, beta, t);
+}
 
 // ---------------------------------------------------------------- kd-tree
 struct KdStackEntry { int32_t node; double t_near, t_far; };
+constexpr int SMALL_LEAF = 24;     // leaves up to this size are scanned by the lane that reached them
 
 // BoundingBox.hit (geometry.py:49-70) on the tree's root box.
 __device__ __forceinline__ bool root_box(const rtamd_tree& T, const Ray& r, double& tmin, double& tmax) {
@@ -151,84 +182,151 @@ __device__ __forceinline__ bool root_box(const rtamd_tree& T, const Ray& r, doub
     return true;
 }
 
-// Front-to-back leaf walk of KDTree.iterate_nodes (kdtree.py:133-155).  `LeafFn(first,
-// count)` returns true to stop the walk (the closest-hit and shadow queries both stop at
-// the first leaf that yields a hit).
-template <bool COUNT, class LeafFn>
-__device__ __forceinline__ void kd_walk(const rtamd_scene_desc& S, const rtamd_tree& T, const Ray& r,
-                                        Work<COUNT>& w, LeafFn&& leaf_fn) {
-    double t_near, t_far;
-    if (!root_box(T, r, t_near, t_far)) return;
+struct TriHit { double t, alpha, beta; int32_t ref; };
+
+// One kd-tree query per active lane, all 64 lanes inside.
+//
+// Each lane walks the tree front to back exactly as KDTree.iterate_nodes does
+// (kdtree.py:133-155) with a private stack.  When lanes arrive at leaves:
+//   * a small leaf is scanned by its own lane;
+//   * a big leaf is handed to the wave: its ray is broadcast and the 64 lanes test 64
+//     consecutive leaf references per step (coalesced loads of the SoA table).
+// SHADOW = false is KDTree.hit (kdtree.py:166-174): every item of the leaf is tested, the
+// strict minimum t wins, ties go to the earlier item, and the walk ends at the first leaf
+// with a hit.  SHADOW = true is KDTree.shadow_hit (kdtree.py:157-164): the first item in
+// leaf order that reports a hit ends the query and its t is returned.
+template <bool COUNT, bool SHADOW>
+__device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool active, const Ray& r,
+                              Work<COUNT>& w, bool& found, TriHit& best) {
+    found = false;
+    double t_near = 0, t_far = 0;
+    bool walking = active && root_box(T, r, t_near, t_far);
     KdStackEntry stack[STACK_MAX];
     int sp = 0;
     int32_t node = T.node_offset;
-    for (;;) {
-        rtamd_kdnode nd = S.kd_nodes[node];
-        while ((nd.b & 3) != 3) {
-            w.node();
-            const int ax = nd.b;
-            const double o = axis_of(r.o, ax), d = axis_of(r.d, ax);
-            const double t = (nd.split - o) / d;
-            int32_t near_n, far_n;
-            if (nd.split >= o) { near_n = node + 1; far_n = nd.a; }
-            else               { near_n = nd.a;     far_n = node + 1; }
-            if (t >= t_far || t < 0) {
-                node = near_n;
-            } else if (t <= t_near) {
-                node = far_n;
+    const int lane = lane_id();
+    const int64_t nref = S.n_refs;
+    const double* __restrict__ geom = S.tri_geom;
+
+    while (__ballot(walking)) {
+        int32_t first = 0, count = 0;
+        if (walking) {
+            rtamd_kdnode nd = S.kd_nodes[node];
+            while ((nd.b & 3) != 3) {
+                w.node();
+                const int ax = nd.b;
+                const double o = axis_of(r.o, ax), d = axis_of(r.d, ax);
+                const double t = (nd.split - o) / d;
+                int32_t near_n, far_n;
+                if (nd.split >= o) { near_n = node + 1; far_n = nd.a; }
+                else               { near_n = nd.a;     far_n = node + 1; }
+                if (t >= t_far || t < 0) {
+                    node = near_n;
+                } else if (t <= t_near) {
+                    node = far_n;
+                } else {
+                    stack[sp].node = far_n; stack[sp].t_near = t; stack[sp].t_far = t_far;
+                    sp++;
+                    node = near_n;
+                    t_far = t;
+                }
+                nd = S.kd_nodes[node];
+            }
+            w.leaf();
+            first = nd.a;
+            count = nd.b >> 2;
+        }
+
+        const bool small = walking && count <= SMALL_LEAF;
+        if (small) {
+            if (SHADOW) {
+                for (int32_t i = 0; i < count; ++i) {
+                    if (S.tri_prim[first + i] & NO_SHADOW_BIT) continue;         // geometry.py:433-434
+                    w.tri(1);
+                    double a, b, t;
+                    if (tri_solve_ref(geom, nref, first + i, r, a, b, t)) { best.t = t; found = true; break; }
+                }
             } else {
-                stack[sp].node = far_n; stack[sp].t_near = t; stack[sp].t_far = t_far;
-                sp++;
-                node = near_n;
-                t_far = t;
+                w.tri((uint32_t)count);
+                for (int32_t i = 0; i < count; ++i) {
+                    double a, b, t;
+                    if (tri_solve_ref(geom, nref, first + i, r, a, b, t) && (!found || best.t > t)) {
+                        best.t = t; best.alpha = a; best.beta = b; best.ref = first + i; found = true;
+                    }
+                }
             }
-            nd = S.kd_nodes[node];
         }
-        w.leaf();
-        if (leaf_fn(nd.a, nd.b >> 2)) return;
-        if (sp == 0) return;
-        sp--;
-        node = stack[sp].node; t_near = stack[sp].t_near; t_far = stack[sp].t_far;
+
+        unsigned long long big = __ballot(walking && !small);
+        while (big) {
+            const int src = first_lane(big);
+            big &= big - 1;
+            Ray q;
+            q.o = v3(bcast_d(r.o.x, src), bcast_d(r.o.y, src), bcast_d(r.o.z, src));
+            q.d = v3(bcast_d(r.d.x, src), bcast_d(r.d.y, src), bcast_d(r.d.z, src));
+            const int32_t qfirst = bcast_i(first, src), qcount = bcast_i(count, src);
+            if (SHADOW) {
+                bool hit_any = false;
+                double t_hit = 0;
+                uint32_t tests = 0;
+                for (int32_t c = 0; c < qcount; c += 64) {
+                    const int32_t i = c + lane;
+                    const bool cast = i < qcount && !(S.tri_prim[qfirst + i] & NO_SHADOW_BIT);
+                    double a, b, t = 0;
+                    const bool hit = cast && tri_solve_ref(geom, nref, qfirst + i, q, a, b, t);
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm) {
+                        const int l = first_lane(hm);
+                        t_hit = bcast_d(t, l);
+                        hit_any = true;
+                        if (COUNT) tests += (uint32_t)__popcll(__ballot(cast) & ((2ull << l) - 1ull));
+                        break;
+                    }
+                    if (COUNT) tests += (uint32_t)__popcll(__ballot(cast));
+                }
+                if (lane == src) {
+                    w.tri(tests);
+                    if (hit_any) { best.t = t_hit; found = true; }
+                }
+            } else {
+                bool lfound = false;
+                double lt = 0, la = 0, lb = 0;
+                int32_t lref = 0;
+                for (int32_t c = 0; c < qcount; c += 64) {
+                    const int32_t i = c + lane;
+                    double a, b, t;
+                    if (i < qcount && tri_solve_ref(geom, nref, qfirst + i, q, a, b, t) && (!lfound || lt > t)) {
+                        lt = t; la = a; lb = b; lref = qfirst + i; lfound = true;
+                    }
+                }
+                unsigned long long cand = __ballot(lfound);
+                if (cand) {
+                    // lexicographic minimum of (t, leaf position) over the lanes that found a hit
+                    int l = first_lane(cand);
+                    for (;;) {
+                        const double tl = bcast_d(lt, l);
+                        const int32_t rl = bcast_i(lref, l);
+                        cand = __ballot(lfound && (lt < tl || (lt == tl && lref < rl)));
+                        if (!cand) break;
+                        l = first_lane(cand);
+                    }
+                    const double wt = bcast_d(lt, l), wa = bcast_d(la, l), wb = bcast_d(lb, l);
+                    const int32_t wr = bcast_i(lref, l);
+                    if (lane == src) { best.t = wt; best.alpha = wa; best.beta = wb; best.ref = wr; found = true; }
+                }
+                if (lane == src) w.tri((uint32_t)qcount);
+            }
+        }
+
+        if (walking) {
+            if (found || sp == 0) {
+                walking = false;
+            } else {
+                sp--;
+                node = stack[sp].node; t_near = stack[sp].t_near; t_far = stack[sp].t_far;
+            }
+        }
     }
-}
-
-struct TriHit { double t, alpha, beta; int32_t ref; };
-
-// KDTree.hit (kdtree.py:166-174): all items of a leaf are tested, the strict minimum t
-// wins (first item on ties), and the walk ends at the first leaf that produced a hit.
-template <bool COUNT>
-__device__ __forceinline__ bool kd_closest(const rtamd_scene_desc& S, const rtamd_tree& T, const Ray& r,
-                                           Work<COUNT>& w, TriHit& best) {
-    bool found = false;
-    kd_walk<COUNT>(S, T, r, w, [&](int32_t first, int32_t count) {
-        w.tri((uint32_t)count);
-        for (int32_t i = 0; i < count; ++i) {
-            double a, b, t;
-            if (tri_solve(S.tri_geom + 9 * (int64_t)(first + i), r, a, b, t)) {
-                if (!found || best.t > t) { best.t = t; best.alpha = a; best.beta = b; best.ref = first + i; found = true; }
-            }
-        }
-        return found;
-    });
-    return found;
-}
-
-// KDTree.shadow_hit (kdtree.py:157-164): the first item, in leaf order, that reports a
-// hit ends the query; its t is returned whatever the caller's distance bound is.
-template <bool COUNT>
-__device__ __forceinline__ bool kd_shadow(const rtamd_scene_desc& S, const rtamd_tree& T, const Ray& r,
-                                          Work<COUNT>& w, double& t_out) {
-    bool found = false;
-    kd_walk<COUNT>(S, T, r, w, [&](int32_t first, int32_t count) {
-        for (int32_t i = 0; i < count; ++i) {
-            if (S.tri_prim[first + i] & NO_SHADOW_BIT) continue;     // geometry.py:433-434
-            w.tri(1);
-            double a, b, t;
-            if (tri_solve(S.tri_geom + 9 * (int64_t)(first + i), r, a, b, t)) { t_out = t; found = true; return true; }
-        }
-        return false;
-    });
-    return found;
 }
 
 // ---------------------------------------------------------------- analytic primitives
@@ -338,10 +436,10 @@ struct Hit {
     int32_t material, object, prim;
 };
 
-// World.hit_objects (main.py:35-46): objects in list order, strict `<`.
+// World.hit_objects (main.py:35-46) for every active lane: objects in list order, strict `<`.
 template <bool COUNT>
-__device__ bool closest_hit(const rtamd_scene_desc& S, const Ray& ray, Work<COUNT>& w, Hit& h) {
-    w.closest++;
+__device__ bool closest_hit_wave(const rtamd_scene_desc& S, bool active, const Ray& ray, Work<COUNT>& w, Hit& h) {
+    if (active) w.closest++;
     double tmin = T_INF;
     bool any = false;
     for (int i = 0; i < S.n_objects; ++i) {
@@ -352,58 +450,63 @@ __device__ bool closest_hit(const rtamd_scene_desc& S, const Ray& ray, Work<COUN
         V3 n = v3(0, 0, 0);
         int32_t mat = ob.material, prim = -1;
         bool hit = false;
-        if (ob.kind != RTAMD_KDTREE) w.analytic();
-        switch (ob.kind) {
-        case RTAMD_SPHERE: {
-            V3 temp;
-            hit = sphere_t(p, r, temp, t);
-            if (hit) n = ((temp + t * r.d) / p[3]) * p[4];
-        } break;
-        case RTAMD_PLANE:
-            hit = plane_t(ld3(p), ld3(p + 3), r, t);
-            n = ld3(p + 3);
-            break;
-        case RTAMD_CHECKER_PLANE:
-            hit = plane_t(ld3(p), ld3(p + 3), r, t);
-            n = ld3(p + 3);
-            if (hit) {                                        // geometry.py:353-360
-                const V3 rel = (r.o + t * r.d) - ld3(p);
-                const double x = round(dot(rel, ld3(p + 6)) / p[12]);
-                const double y = round(dot(rel, ld3(p + 9)) / p[12]);
-                if (fmod(x + y, 2.0) != 0) mat = ob.alt_material;
+        if (ob.kind == RTAMD_KDTREE) {
+            if (__ballot(active)) {
+                const rtamd_tree& T = S.trees[ob.tree];
+                TriHit th;
+                bool f;
+                kd_query_wave<COUNT, false>(S, T, active, r, w, f, th);
+                if (active && f) {
+                    hit = true;
+                    t = th.t;
+                    prim = S.tri_prim[th.ref] & (NO_SHADOW_BIT - 1);
+                    const int64_t gp = (int64_t)T.prim_offset + prim;
+                    const double* nn = S.prim_normals + S.prim_normal_offset[gp];
+                    n = T.smooth ? ((1 - th.alpha - th.beta) * ld3(nn) + th.alpha * ld3(nn + 3)) + th.beta * ld3(nn + 6)
+                                 : ld3(nn);
+                    mat = S.prim_material[gp];
+                }
             }
-            break;
-        case RTAMD_RECTANGLE:
-            hit = rectangle_t(p, r, t);
-            n = ld3(p + 3);
-            break;
-        case RTAMD_BOX:
-            hit = box_hit(p, r, t, n);
-            break;
-        case RTAMD_TRIANGLE: {
-            const double g[9] = {p[0], p[1], p[2], p[3] - p[0], p[4] - p[1], p[5] - p[2],
-                                 p[6] - p[0], p[7] - p[1], p[8] - p[2]};
-            double a, b;
-            hit = tri_solve(g, r, a, b, t);
-            if (hit) n = ob.smooth ? ((1 - a - b) * ld3(p + 12) + a * ld3(p + 15)) + b * ld3(p + 18) : ld3(p + 9);
-        } break;
-        case RTAMD_KDTREE: {
-            const rtamd_tree& T = S.trees[ob.tree];
-            TriHit th;
-            hit = kd_closest<COUNT>(S, T, r, w, th);
-            if (hit) {
-                t = th.t;
-                prim = S.tri_prim[th.ref] & (NO_SHADOW_BIT - 1);
-                const int64_t gp = (int64_t)T.prim_offset + prim;
-                const double* nn = S.prim_normals + S.prim_normal_offset[gp];
-                n = T.smooth ? ((1 - th.alpha - th.beta) * ld3(nn) + th.alpha * ld3(nn + 3)) + th.beta * ld3(nn + 6)
-                             : ld3(nn);
-                mat = S.prim_material[gp];
+        } else if (active) {
+            w.analytic();
+            switch (ob.kind) {
+            case RTAMD_SPHERE: {
+                V3 temp;
+                hit = sphere_t(p, r, temp, t);
+                if (hit) n = ((temp + t * r.d) / p[3]) * p[4];
+            } break;
+            case RTAMD_PLANE:
+                hit = plane_t(ld3(p), ld3(p + 3), r, t);
+                n = ld3(p + 3);
+                break;
+            case RTAMD_CHECKER_PLANE:
+                hit = plane_t(ld3(p), ld3(p + 3), r, t);
+                n = ld3(p + 3);
+                if (hit) {                                        // geometry.py:353-360
+                    const V3 rel = (r.o + t * r.d) - ld3(p);
+                    const double x = round(dot(rel, ld3(p + 6)) / p[12]);
+                    const double y = round(dot(rel, ld3(p + 9)) / p[12]);
+                    if (fmod(x + y, 2.0) != 0) mat = ob.alt_material;
+                }
+                break;
+            case RTAMD_RECTANGLE:
+                hit = rectangle_t(p, r, t);
+                n = ld3(p + 3);
+                break;
+            case RTAMD_BOX:
+                hit = box_hit(p, r, t, n);
+                break;
+            case RTAMD_TRIANGLE: {
+                const double g[9] = {p[0], p[1], p[2], p[3] - p[0], p[4] - p[1], p[5] - p[2],
+                                     p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+                double a, b;
+                hit = tri_solve(g, r, a, b, t);
+                if (hit) n = ob.smooth ? ((1 - a - b) * ld3(p + 12) + a * ld3(p + 15)) + b * ld3(p + 18) : ld3(p + 9);
+            } break;
+            default: break;
             }
-        } break;
-        default: break;
         }
-        if (hit && t < tmin) {
+        if (active && hit && t < tmin) {
             tmin = t;
             any = true;
             h.t = t;
@@ -417,41 +520,48 @@ __device__ bool closest_hit(const rtamd_scene_desc& S, const Ray& ray, Work<COUN
     return any;
 }
 
-// obj.shadow_hit for one world object.
+// light.in_shadow for every lane with `need`: any object that reports a hit [closer than
+// `limit`] (light.py:31-37 / :124-130 with a distance, :60-65 / :78-83 / :170-175 without).
 template <bool COUNT>
-__device__ __forceinline__ bool shadow_hit(const rtamd_scene_desc& S, const rtamd_object& ob, const Ray& ray,
-                                           Work<COUNT>& w, double& t) {
-    const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
-    const double* p = ob.p;
-    if (ob.kind == RTAMD_KDTREE) return kd_shadow<COUNT>(S, S.trees[ob.tree], r, w, t);
-    if (!ob.cast_shadow) return false;
-    w.analytic();
-    switch (ob.kind) {
-    case RTAMD_SPHERE: { V3 temp; return sphere_t(p, r, temp, t); }
-    case RTAMD_PLANE:
-    case RTAMD_CHECKER_PLANE: return plane_t(ld3(p), ld3(p + 3), r, t);
-    case RTAMD_RECTANGLE: return rectangle_t(p, r, t);
-    case RTAMD_BOX: return box_shadow(p, r, t);
-    case RTAMD_TRIANGLE: {
-        const double g[9] = {p[0], p[1], p[2], p[3] - p[0], p[4] - p[1], p[5] - p[2],
-                             p[6] - p[0], p[7] - p[1], p[8] - p[2]};
-        double a, b;
-        return tri_solve(g, r, a, b, t);
-    }
-    default: return false;
-    }
-}
-
-// light.in_shadow: any object that reports a hit [closer than `limit`]
-// (light.py:31-37 with a distance, :60-65 / :78-83 / :170-175 without).
-template <bool COUNT>
-__device__ bool occluded(const rtamd_scene_desc& S, const Ray& ray, bool use_limit, double limit, Work<COUNT>& w) {
-    w.shadow++;
+__device__ bool occluded_wave(const rtamd_scene_desc& S, bool need, const Ray& ray, bool use_limit, double limit,
+                              Work<COUNT>& w) {
+    if (need) w.shadow++;
+    bool occ = false;
     for (int i = 0; i < S.n_objects; ++i) {
-        double t;
-        if (shadow_hit<COUNT>(S, S.objects[i], ray, w, t) && (!use_limit || t < limit)) return true;
+        const rtamd_object& ob = S.objects[i];
+        const bool q = need && !occ;
+        const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+        const double* p = ob.p;
+        double t = 0;
+        bool hit = false;
+        if (ob.kind == RTAMD_KDTREE) {
+            if (__ballot(q)) {
+                TriHit th;
+                bool f;
+                kd_query_wave<COUNT, true>(S, S.trees[ob.tree], q, r, w, f, th);
+                hit = q && f;
+                t = th.t;
+            }
+        } else if (q && ob.cast_shadow) {
+            w.analytic();
+            switch (ob.kind) {
+            case RTAMD_SPHERE: { V3 temp; hit = sphere_t(p, r, temp, t); } break;
+            case RTAMD_PLANE:
+            case RTAMD_CHECKER_PLANE: hit = plane_t(ld3(p), ld3(p + 3), r, t); break;
+            case RTAMD_RECTANGLE: hit = rectangle_t(p, r, t); break;
+            case RTAMD_BOX: hit = box_shadow(p, r, t); break;
+            case RTAMD_TRIANGLE: {
+                const double g[9] = {p[0], p[1], p[2], p[3] - p[0], p[4] - p[1], p[5] - p[2],
+                                     p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+                double a, b;
+                hit = tri_solve(g, r, a, b, t);
+            } break;
+            default: break;
+            }
+        }
+        if (q && hit && (!use_limit || t < limit)) occ = true;
     }
-    return false;
+    return occ;
 }
 
 // ---------------------------------------------------------------- shading
@@ -464,16 +574,6 @@ __device__ __forceinline__ V3 hemisphere_about(V3 w, V3 sp) {
     return (u * sp.x + v * sp.y) + w * sp.z;
 }
 
-// ambient_color.L(sr): AmbientLight (light.py:14-15) or AmbientOccluder (light.py:85-100).
-template <bool COUNT>
-__device__ __forceinline__ V3 ambient_radiance(const rtamd_scene_desc& S, const Hit& h, Draw& dr, Work<COUNT>& w) {
-    if (S.ambient.kind == RTAMD_AMBIENT_CONSTANT) return ld3(S.ambient.radiance);
-    Ray sr;
-    sr.o = h.p;
-    sr.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
-    return occluded<COUNT>(S, sr, false, 0.0, w) ? ld3(S.ambient.occluded) : ld3(S.ambient.radiance);
-}
-
 // GlossySpecular.f (material.py:88-97) with ks*cs folded into `spec`.
 __device__ __forceinline__ V3 phong_lobe(V3 spec, double exp_, V3 n, V3 wo, V3 wi) {
     const double ndotwi = dot(n, wi);
@@ -483,52 +583,63 @@ __device__ __forceinline__ V3 phong_lobe(V3 spec, double exp_, V3 n, V3 wo, V3 w
     return v3(0, 0, 0);
 }
 
-// The direct-lighting loop shared by Matte/Phong .shade and .area_light_shade
-// (material.py:251-281, :346-377).  `area` selects the G/pdf weighting.
+// The direct-lighting sum of Matte/Phong .shade and .area_light_shade (material.py:251-281,
+// :346-377) for every lane with `lit`; `area` selects the G/pdf weighting.  Lights are
+// visited in list order by the whole wave so that the shadow queries stay wave-wide.
 template <bool COUNT>
-__device__ V3 direct_light(const rtamd_scene_desc& S, const rtamd_material& m, const Hit& h, V3 wo,
-                           bool area, Draw& dr, Work<COUNT>& w) {
-    V3 L = ld3(m.ambient) * ambient_radiance<COUNT>(S, h, dr, w);
+__device__ V3 direct_light_wave(const rtamd_scene_desc& S, bool lit, const rtamd_material& m, const Hit& h, V3 wo,
+                                bool area, Draw& dr, Work<COUNT>& w) {
+    // ambient_color.L(sr): AmbientLight (light.py:14-15) or AmbientOccluder (light.py:85-100)
+    V3 amb = ld3(S.ambient.radiance);
+    if (S.ambient.kind == RTAMD_AMBIENT_OCCLUDER) {
+        Ray sr;
+        sr.o = h.p;
+        sr.d = v3(0, 0, 1);
+        if (lit) sr.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
+        if (occluded_wave<COUNT>(S, lit, sr, false, 0.0, w)) amb = ld3(S.ambient.occluded);
+    }
+    V3 L = ld3(m.ambient) * amb;
     const bool phong = m.kind != RTAMD_MATTE;
     // Matte.shade alone ignores receives_shadow (material.py:263 vs :279, :358, :374)
     const bool gate = (phong || area) ? (m.receives_shadow != 0) : true;
     for (int li = 0; li < S.n_lights; ++li) {
         const rtamd_light& lt = S.lights[li];
-        V3 wi, sample_point = v3(0, 0, 0);
-        switch (lt.kind) {
-        case RTAMD_POINT: {                                  // light.py:27-29
-            const V3 v = ld3(lt.position) - h.p;
-            wi = v / norm(v);
-        } break;
-        case RTAMD_DIRECTIONAL:                              // light.py:54-55
-            wi = ld3(lt.position);
-            break;
-        case RTAMD_AREA: {                                   // light.py:116-122, geometry.py:378-380
-            double sx, sy;
-            draw_square(S, lt.sampler, dr, sx, sy);
-            sample_point = (ld3(lt.position) + sx * ld3(lt.edge_u)) + sy * ld3(lt.edge_v);
-            const V3 v = sample_point - h.p;
-            wi = v / norm(v);
-        } break;
-        default:                                             // ENVIRONMENT, light.py:152-165
-            wi = hemisphere_about(h.n, draw_hemisphere(S, lt.sampler, dr));
-            break;
+        V3 wi = v3(0, 0, 1), sample_point = v3(0, 0, 0);
+        if (lit) {
+            switch (lt.kind) {
+            case RTAMD_POINT: {                                  // light.py:27-29
+                const V3 v = ld3(lt.position) - h.p;
+                wi = v / norm(v);
+            } break;
+            case RTAMD_DIRECTIONAL:                              // light.py:54-55
+                wi = ld3(lt.position);
+                break;
+            case RTAMD_AREA: {                                   // light.py:116-122, geometry.py:378-380
+                double sx, sy;
+                draw_square(S, lt.sampler, dr, sx, sy);
+                sample_point = (ld3(lt.position) + sx * ld3(lt.edge_u)) + sy * ld3(lt.edge_v);
+                const V3 v = sample_point - h.p;
+                wi = v / norm(v);
+            } break;
+            default:                                             // ENVIRONMENT, light.py:152-165
+                wi = hemisphere_about(h.n, draw_hemisphere(S, lt.sampler, dr));
+                break;
+            }
         }
         const double ndotwi = dot(h.n, wi);
-        if (!(ndotwi > 0)) continue;
+        const bool facing = lit && ndotwi > 0;
         bool in_shadow = false;
         if (lt.cast_shadow) {
             Ray sr;
             sr.o = h.p;
             sr.d = wi;
-            if (lt.kind == RTAMD_POINT)
-                in_shadow = occluded<COUNT>(S, sr, true, norm(sr.o - ld3(lt.position)), w);      // light.py:32
-            else if (lt.kind == RTAMD_AREA)
-                in_shadow = occluded<COUNT>(S, sr, true, dot(sample_point - sr.o, sr.d), w);      // light.py:125
-            else
-                in_shadow = occluded<COUNT>(S, sr, false, 0.0, w);
+            double limit = 0;
+            if (lt.kind == RTAMD_POINT) limit = norm(sr.o - ld3(lt.position));                    // light.py:32
+            else if (lt.kind == RTAMD_AREA) limit = dot(sample_point - sr.o, sr.d);               // light.py:125
+            const bool bounded = lt.kind == RTAMD_POINT || lt.kind == RTAMD_AREA;
+            if (__ballot(facing)) in_shadow = occluded_wave<COUNT>(S, facing, sr, bounded, limit, w);
         }
-        if (in_shadow || !gate) continue;
+        if (!facing || in_shadow || !gate) continue;
         V3 f = ld3(m.diffuse);
         if (phong) f = f + phong_lobe(ld3(m.specular), m.exp, h.n, wo, wi);
         V3 Ll = ld3(lt.radiance);
@@ -554,52 +665,62 @@ __device__ V3 direct_light(const rtamd_scene_desc& S, const rtamd_material& m, c
 
 struct Primary { int32_t object, prim; double t; };
 
-// tracer.trace_ray (tracer.py:26-35, :65-71, :79-88) with the single-child recursion of
-// Reflective / GlossyReflective / Matte.path_shade (material.py:385-411, :283-289)
-// unrolled into a loop: radiance = sum over bounces of (product of child weights) * local.
+// tracer.trace_ray (tracer.py:26-35, :65-71, :79-88) for the 64 samples of a wave.  The
+// single-child recursion of Reflective / GlossyReflective / Matte.path_shade
+// (material.py:385-411, :283-289) is unrolled into a loop: radiance = sum over bounces of
+// (product of the child weights so far) * local term.  Lanes whose path has ended stay in
+// the loop as helpers for the wave-wide kd leaf tests until every lane is done.
 template <bool COUNT>
-__device__ V3 trace(const rtamd_scene_desc& S, Ray ray, int depth, Draw& dr, Work<COUNT>& w, Primary& first) {
+__device__ V3 trace_wave(const rtamd_scene_desc& S, bool alive, Ray ray, int depth, Draw& dr, Work<COUNT>& w,
+                         Primary& first) {
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
     const V3 background = (S.tracer_kind == RTAMD_TRACER_SHADE) ? ld3(S.background) : v3(0, 0, 0);
+    const bool area = S.tracer_kind == RTAMD_TRACER_AREA;
     first.object = -1; first.prim = -1; first.t = 0;
     bool primary = true;
     for (;; ++depth) {
-        if (S.tracer_kind != RTAMD_TRACER_AREA && depth > S.depth_limit) { L = L + W * background; break; }
+        if (alive && !area && depth > S.depth_limit) { L = L + W * background; alive = false; }
+        if (!__ballot(alive)) break;
         Hit h;
-        if (!closest_hit<COUNT>(S, ray, w, h)) { L = L + W * background; break; }
-        if (primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; primary = false; }
-        const rtamd_material& m = S.materials[h.material];
+        h.p = v3(0, 0, 0); h.n = v3(0, 0, 1); h.material = 0;
+        const bool hit = closest_hit_wave<COUNT>(S, alive, ray, w, h);
+        if (alive && !hit) { L = L + W * background; alive = false; }
+        if (alive && primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; }
+        primary = false;
+        const rtamd_material& m = S.materials[alive ? h.material : 0];
         const V3 wo = -ray.d;
 
-        if (m.kind == RTAMD_EMISSIVE) {
+        if (alive && m.kind == RTAMD_EMISSIVE) {
             V3 e;
             if (S.tracer_kind == RTAMD_TRACER_SHADE) e = v3(1., 1., 1.);                           // material.py:495-496
-            else if (S.tracer_kind == RTAMD_TRACER_AREA)
-                e = (-dot(h.n, ray.d) > 0) ? ld3(m.emit) : v3(0, 0, 0);                             // material.py:498-502
+            else if (area) e = (-dot(h.n, ray.d) > 0) ? ld3(m.emit) : v3(0, 0, 0);                  // material.py:498-502
             else e = (dot(h.n, ray.d) < 0) ? ld3(m.emit) : v3(0, 0, 0);                             // material.py:504-508
             L = L + W * e;
-            break;
+            alive = false;
         }
 
         if (S.tracer_kind == RTAMD_TRACER_PATH) {
-            // Lambertian.sample_f (material.py:41-53) then Matte.path_shade (:283-289)
-            V3 v = cross(v3(0.0034, 1, 0.0071), h.n);
-            v = v / norm(v);
-            const V3 u = cross(v, h.n);
-            const V3 sp = draw_hemisphere(S, m.sampler, dr);
-            V3 wi = (sp.x * u + sp.y * v) + sp.z * h.n;
-            wi = wi / norm(wi);
-            const double pdf = dot(h.n, wi) / PI;
-            const double ndotwi = dot(h.n, wi);
-            W = W * ((ld3(m.diffuse) * ndotwi) / pdf);
-            ray.o = h.p;
-            ray.d = wi;
+            if (alive) {
+                // Lambertian.sample_f (material.py:41-53) then Matte.path_shade (:283-289)
+                V3 v = cross(v3(0.0034, 1, 0.0071), h.n);
+                v = v / norm(v);
+                const V3 u = cross(v, h.n);
+                const V3 sp = draw_hemisphere(S, m.sampler, dr);
+                V3 wi = (sp.x * u + sp.y * v) + sp.z * h.n;
+                wi = wi / norm(wi);
+                const double pdf = dot(h.n, wi) / PI;
+                const double ndotwi = dot(h.n, wi);
+                W = W * ((ld3(m.diffuse) * ndotwi) / pdf);
+                ray.o = h.p;
+                ray.d = wi;
+            }
             continue;
         }
 
-        const bool area = S.tracer_kind == RTAMD_TRACER_AREA;
-        L = L + W * direct_light<COUNT>(S, m, h, wo, area, dr, w);
-        if (area) break;
+        const V3 Ld = direct_light_wave<COUNT>(S, alive, m, h, wo, area, dr, w);
+        if (alive) L = L + W * Ld;
+        if (area) { alive = false; continue; }
+        if (!alive) continue;
 
         if (m.kind == RTAMD_REFLECTIVE) {
             // PerfectSpecular.sample_f (material.py:69-74), Reflective.shade (:385-394)
@@ -629,7 +750,7 @@ __device__ V3 trace(const rtamd_scene_desc& S, Ray ray, int depth, Draw& dr, Wor
             ray.o = h.p;
             ray.d = wi;
         } else {
-            break;
+            alive = false;
         }
     }
     return L;

@@ -58,9 +58,9 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(const rtamd_scene_desc S, 
     Work<COUNT> work;
     int64_t acc_row = -1;
 
+    Ray ray;
+    int32_t pixel = 0, sample = 0;
     if (live) {
-        Ray ray;
-        int32_t pixel = 0, sample = 0;
         if (MODE == MODE_RAYS) {
             pixel = A.pixel_index ? A.pixel_index[k] : 0;
             sample = A.sample_index ? A.sample_index[k] : 0;
@@ -107,14 +107,17 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(const rtamd_scene_desc S, 
             }
         }
 
+    }
+    // every lane of the wave enters the trace; lanes without a sample only help
+    {
+        if (!live) { ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); }
+        Draw dr;
+        dr.key = mix64(A.trace_key ^ (uint64_t)(uint32_t)pixel);
+        dr.sample = (uint32_t)sample;
+        dr.counter = 0;
+        Primary first;
+        const V3 c = trace_wave<COUNT>(S, live, ray, A.depth0, dr, work, first);
         if (live) {
-            Draw dr;
-            dr.key = mix64(A.trace_key ^ (uint64_t)(uint32_t)pixel);
-            dr.sample = (uint32_t)sample;
-            dr.counter = 0;
-            Primary first;
-            const V3 c = trace<COUNT>(S, ray, A.depth0, dr, work, first);
-
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
             if (A.out.rgb) { A.out.rgb[3 * k] = c.x; A.out.rgb[3 * k + 1] = c.y; A.out.rgb[3 * k + 2] = c.z; }
             if (A.out.rgb8) { A.out.rgb8[3 * k] = r8; A.out.rgb8[3 * k + 1] = g8; A.out.rgb8[3 * k + 2] = b8; }

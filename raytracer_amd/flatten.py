@@ -170,7 +170,7 @@ class _Flattener(object):
         geom[:, 0:3] = v0[refs]
         geom[:, 3:6] = v1[refs] - v0[refs]
         geom[:, 6:9] = v2[refs] - v0[refs]
-        self.tri_geom.append(geom.ravel())
+        self.tri_geom.append(geom)
         self.tri_prim.append((refs.astype(numpy.int32) | flags[refs]).astype(numpy.int32))
 
         # nodes (preorder; left child = next node)
@@ -336,7 +336,9 @@ def flatten_world(world):
     a["trees"] = pack(fl.trees, capi.Tree)
     a["kd_nodes"] = (numpy.concatenate(fl.kd_nodes).view(numpy.uint8) if fl.kd_nodes
                      else numpy.zeros(0, numpy.uint8))
-    a["tri_geom"] = _cat(fl.tri_geom, numpy.float64)
+    # struct of arrays over all leaf references of all trees: [9][n_refs]
+    a["tri_geom"] = (numpy.ascontiguousarray(numpy.concatenate(fl.tri_geom, axis=0).T).ravel()
+                     if fl.tri_geom else numpy.zeros(0, numpy.float64))
     a["tri_prim"] = _cat(fl.tri_prim, numpy.int32)
     a["prim_normals"] = _cat(fl.prim_normals, numpy.float64)
     a["prim_normal_offset"] = _cat(fl.prim_normal_offset, numpy.int64)
