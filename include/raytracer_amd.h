@@ -145,7 +145,8 @@ typedef struct rtamd_sampler {
 
 /* 16-byte kd node; nodes of a tree are stored in preorder, so the left child of node i
  * is node i+1.  Interior: split plane, a = index of the right child, b = axis (0..2).
- * Leaf: b & 3 == 3, a = first leaf reference, b >> 2 = reference count.
+ * Leaf: b & 3 == 3, a = first leaf reference, b >> 2 = reference count; `split` of a leaf
+ * is the index of its first chunk box when the leaf has them (see chunk_boxes), else < 0.
  * Node and reference indices are absolute (into kd_nodes / tri_* of the scene). */
 typedef struct rtamd_kdnode {
     double split;
@@ -172,6 +173,13 @@ typedef struct rtamd_tree {
  *                       lanes of a wave load 64 consecutive references with 9 coalesced reads
  *   tri_prim[ref]     = primitive index within its tree; bit 30 set if the triangle
  *                       does not cast shadows (geometry.py:433-434)
+ *   tri_order[ref]    = position of the row in the reference's scan order (absolute
+ *                       reference index).  Rows of a leaf may be stored in any order;
+ *                       ties in t and "first item that hits" are decided by this value.
+ *                       NULL means rows are stored in scan order.
+ *   chunk_boxes[6][n_chunks] = lo.xyz, hi.xyz of each 64-row chunk of the leaves that carry
+ *                       boxes (conservative: every triangle of the chunk lies inside);
+ *                       may be NULL with n_chunks = 0
  * Per-primitive tables (one row per triangle, all trees concatenated):
  *   prim_normals      = unit face normal [3], or n0,n1,n2 [9] for smooth trees; rows
  *                       are addressed through prim_normal_offset[prim] (in doubles)
@@ -190,6 +198,7 @@ typedef struct rtamd_scene_desc {
     int64_t n_refs;
     int64_t n_prims;
     int64_t n_sampler_doubles;
+    int64_t n_chunks;
     double background[3];
     rtamd_ambient ambient;
     const rtamd_object *objects;        /* device */
@@ -201,6 +210,8 @@ typedef struct rtamd_scene_desc {
     const rtamd_kdnode *kd_nodes;       /* device */
     const double *tri_geom;             /* device */
     const int32_t *tri_prim;            /* device */
+    const int32_t *tri_order;           /* device, optional */
+    const double *chunk_boxes;          /* device, optional */
     const double *prim_normals;         /* device */
     const int64_t *prim_normal_offset;  /* device */
     const int32_t *prim_material;       /* device */

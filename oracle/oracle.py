@@ -25,8 +25,7 @@ def build():
 def library():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            build()
+        build()        # make: a no-op when the library is newer than its sources
         lib = C.CDLL(LIB_PATH)
         vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
         lib.rto_render_pixels.restype = C.c_int

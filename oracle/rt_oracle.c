@@ -175,6 +175,23 @@ static void kd_begin(kd_iter *it, const rtamd_scene_desc *S, const rtamd_tree *T
     }
 }
 
+/* Diagnostic: leaf visits and leaf items by leaf size (bucket = bit length of the count).
+ * Only meaningful for single-threaded runs; read and reset with rto_leaf_histogram. */
+static uint64_t g_leaf_hist[32][2];
+
+static void note_leaf(int32_t count) {
+    int b = 0;
+    int32_t c = count;
+    while (c) { b++; c >>= 1; }
+    g_leaf_hist[b][0] += 1;
+    g_leaf_hist[b][1] += (uint64_t)count;
+}
+
+void rto_leaf_histogram(uint64_t *out, int reset) {
+    memcpy(out, g_leaf_hist, sizeof(g_leaf_hist));
+    if (reset) memset(g_leaf_hist, 0, sizeof(g_leaf_hist));
+}
+
 /* next leaf: returns 1 and fills first/count, or 0 when the walk is over */
 static int kd_next(kd_iter *it, work_t *w, int32_t *first, int32_t *count) {
     int32_t node;
@@ -187,7 +204,7 @@ static int kd_next(kd_iter *it, work_t *w, int32_t *first, int32_t *count) {
         int ax;
         double o, d, t;
         int32_t near_n, far_n;
-        if ((nd->b & 3) == 3) { *first = nd->a; *count = nd->b >> 2; w->leaves++; return 1; }
+        if ((nd->b & 3) == 3) { *first = nd->a; *count = nd->b >> 2; w->leaves++; note_leaf(*count); return 1; }
         w->nodes++;
         ax = nd->b;
         o = comp(it->r->o, ax); d = comp(it->r->d, ax);

@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "librtamd.so")
+LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(HERE, "csrc", "librtamd.so")
 
 ABI_VERSION = 1
 N_COUNTERS = 8
@@ -65,11 +65,12 @@ class SceneDesc(C.Structure):
                 ("n_objects", C.c_int32), ("n_materials", C.c_int32), ("n_lights", C.c_int32),
                 ("n_samplers", C.c_int32), ("n_trees", C.c_int32),
                 ("n_kd_nodes", C.c_int64), ("n_refs", C.c_int64), ("n_prims", C.c_int64),
-                ("n_sampler_doubles", C.c_int64),
+                ("n_sampler_doubles", C.c_int64), ("n_chunks", C.c_int64),
                 ("background", d3), ("ambient", Ambient),
                 ("objects", C.c_void_p), ("materials", C.c_void_p), ("lights", C.c_void_p),
                 ("samplers", C.c_void_p), ("sampler_data", C.c_void_p), ("trees", C.c_void_p),
                 ("kd_nodes", C.c_void_p), ("tri_geom", C.c_void_p), ("tri_prim", C.c_void_p),
+                ("tri_order", C.c_void_p), ("chunk_boxes", C.c_void_p),
                 ("prim_normals", C.c_void_p), ("prim_normal_offset", C.c_void_p),
                 ("prim_material", C.c_void_p)]
 

@@ -140,6 +140,9 @@ __device__ __forceinline__ int first_lane(unsigned long long mask) {
 // the resulting inf/NaN is false.
 __device__ __forceinline__ bool tri_solve_v(V3 v0, V3 e1, V3 e2, const Ray& r,
                                             double& alpha, double& beta, double& t) {
+#ifdef RT_TRI_FMA
+#pragma clang fp contract(fast)
+#endif
     const V3 pvec = cross(r.d, e2);
     const double det = dot(e1, pvec);
     const double inv = 1.0 / det;
@@ -167,7 +170,10 @@ __device__ __forceinline__ bool tri_solve_ref(const double* __restrict__ g, int6
 
 // ---------------------------------------------------------------- kd-tree
 struct KdStackEntry { int32_t node; double t_near, t_far; };
-constexpr int SMALL_LEAF = 24;     // leaves up to this size are scanned by the lane that reached them
+#ifndef RT_SMALL_LEAF
+#define RT_SMALL_LEAF 8
+#endif
+constexpr int SMALL_LEAF = RT_SMALL_LEAF;     // leaves up to this size are scanned by the lane that reached them
 
 // BoundingBox.hit (geometry.py:49-70) on the tree's root box.
 __device__ __forceinline__ bool root_box(const rtamd_tree& T, const Ray& r, double& tmin, double& tmax) {
@@ -209,7 +215,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     const double* __restrict__ geom = S.tri_geom;
 
     while (__ballot(walking)) {
-        int32_t first = 0, count = 0;
+        int32_t first = 0, count = 0, cbase = -1;
         if (walking) {
             rtamd_kdnode nd = S.kd_nodes[node];
             while ((nd.b & 3) != 3) {
@@ -235,6 +241,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
             w.leaf();
             first = nd.a;
             count = nd.b >> 2;
+            cbase = S.chunk_boxes ? (int32_t)nd.split : -1;
         }
 
         const bool small = walking && count <= SMALL_LEAF;
@@ -265,57 +272,107 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
             q.o = v3(bcast_d(r.o.x, src), bcast_d(r.o.y, src), bcast_d(r.o.z, src));
             q.d = v3(bcast_d(r.d.x, src), bcast_d(r.d.y, src), bcast_d(r.d.z, src));
             const int32_t qfirst = bcast_i(first, src), qcount = bcast_i(count, src);
-            if (SHADOW) {
-                bool hit_any = false;
-                double t_hit = 0;
-                uint32_t tests = 0;
-                for (int32_t c = 0; c < qcount; c += 64) {
-                    const int32_t i = c + lane;
-                    const bool cast = i < qcount && !(S.tri_prim[qfirst + i] & NO_SHADOW_BIT);
-                    double a, b, t = 0;
-                    const bool hit = cast && tri_solve_ref(geom, nref, qfirst + i, q, a, b, t);
-                    const unsigned long long hm = __ballot(hit);
-                    if (hm) {
-                        const int l = first_lane(hm);
-                        t_hit = bcast_d(t, l);
-                        hit_any = true;
-                        if (COUNT) tests += (uint32_t)__popcll(__ballot(cast) & ((2ull << l) - 1ull));
-                        break;
-                    }
-                    if (COUNT) tests += (uint32_t)__popcll(__ballot(cast));
+            const int32_t qbox = bcast_i(cbase, src);
+            const int32_t n_chunks = (qcount + 63) >> 6;
+            // Per-lane best over the rows this lane tests: for a closest-hit query the
+            // minimum t (earlier scan position on ties), for a shadow query the hit with
+            // the earliest scan position.  `lord` is the row's position in the reference's
+            // scan order, which is what ties and "first item that hits" are decided by.
+            bool lfound = false;
+            double lt = 0, la = 0, lb = 0;
+            int32_t lref = 0, lord = 0;
+            uint32_t tests = 0;
+            bool stop = false;
+
+            auto test_chunk = [&](int32_t c) {
+                const int32_t i = c + lane;
+                const bool in = i < qcount;
+                const int32_t ref = qfirst + i;
+                bool usable = in;
+                if (SHADOW) usable = in && !(S.tri_prim[in ? ref : qfirst] & NO_SHADOW_BIT);   // geometry.py:433-434
+                double a, b, t;
+                if (usable && tri_solve_ref(geom, nref, ref, q, a, b, t)) {
+                    const int32_t ord = S.tri_order ? S.tri_order[ref] : ref;
+                    const bool better = SHADOW ? (!lfound || ord < lord)
+                                               : (!lfound || t < lt || (t == lt && ord < lord));
+                    if (better) { lt = t; la = a; lb = b; lref = ref; lord = ord; lfound = true; }
                 }
-                if (lane == src) {
-                    w.tri(tests);
-                    if (hit_any) { best.t = t_hit; found = true; }
+                if (COUNT && SHADOW && qbox < 0) {
+                    // rows are in scan order here: the reference stops at the first hit
+                    const unsigned long long hm = __ballot(lfound), um = __ballot(usable);
+                    if (hm) { tests += (uint32_t)__popcll(um & ((2ull << first_lane(hm)) - 1ull)); }
+                    else tests += (uint32_t)__popcll(um);
+                }
+            };
+
+            if (qbox >= 0) {
+                // leaf with chunk boxes: lane j tests the box of chunk j against the ray's line,
+                // then the wave visits only the chunks whose box the line touches
+                const double ix = 1.0 / q.d.x, iy = 1.0 / q.d.y, iz = 1.0 / q.d.z;
+                const double* __restrict__ cb = S.chunk_boxes;
+                const int64_t nc = S.n_chunks;
+                for (int32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+                    const int32_t j = c0 + lane;
+                    bool touch = false;
+                    if (j < n_chunks) {
+                        const double* bx = cb + qbox + j;
+                        const double x0 = (bx[0] - q.o.x) * ix, x1 = (bx[3 * nc] - q.o.x) * ix;
+                        const double y0 = (bx[nc] - q.o.y) * iy, y1 = (bx[4 * nc] - q.o.y) * iy;
+                        const double z0 = (bx[2 * nc] - q.o.z) * iz, z1 = (bx[5 * nc] - q.o.z) * iz;
+                        // fmin/fmax drop NaNs (0*inf on a slab boundary), which keeps the test conservative
+                        const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+                        const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+                        touch = !(tn > tf) && !(tf < 0.0);
+                    }
+                    unsigned long long todo = __ballot(touch);
+                    while (todo) {
+                        const int32_t c = (c0 + first_lane(todo)) << 6;
+                        todo &= todo - 1;
+                        test_chunk(c);
+                    }
                 }
             } else {
-                bool lfound = false;
-                double lt = 0, la = 0, lb = 0;
-                int32_t lref = 0;
+                for (int32_t c = 0; c < qcount && !stop; c += 64) {
+                    test_chunk(c);
+                    // rows in scan order: a shadow query is decided by the first chunk with a hit
+                    if (SHADOW && __ballot(lfound)) stop = true;
+                }
+            }
+
+            unsigned long long cand = __ballot(lfound);
+            int winner = 0;
+            if (cand) {
+                // minimum over the lanes: (t, scan position) for closest hits, scan position for shadows
+                winner = first_lane(cand);
+                for (;;) {
+                    const double tw = bcast_d(lt, winner);
+                    const int32_t ow = bcast_i(lord, winner);
+                    cand = SHADOW ? __ballot(lfound && lord < ow)
+                                  : __ballot(lfound && (lt < tw || (lt == tw && lord < ow)));
+                    if (!cand) break;
+                    winner = first_lane(cand);
+                }
+                const double wt = bcast_d(lt, winner), wa = bcast_d(la, winner), wb = bcast_d(lb, winner);
+                const int32_t wr = bcast_i(lref, winner);
+                if (lane == src) { best.t = wt; best.alpha = wa; best.beta = wb; best.ref = wr; found = true; }
+                if (COUNT && SHADOW && qbox >= 0) {
+                    // what the reference's scan would have tested: shadow casters up to the hit
+                    const int32_t ow = bcast_i(lord, winner);
+                    for (int32_t c = 0; c < qcount; c += 64) {
+                        const int32_t i = c + lane;
+                        const bool counted = i < qcount && !(S.tri_prim[qfirst + (i < qcount ? i : 0)] & NO_SHADOW_BIT) &&
+                                             S.tri_order[qfirst + (i < qcount ? i : 0)] <= ow;
+                        tests += (uint32_t)__popcll(__ballot(counted));
+                    }
+                }
+            } else if (COUNT && SHADOW && qbox >= 0) {
                 for (int32_t c = 0; c < qcount; c += 64) {
                     const int32_t i = c + lane;
-                    double a, b, t;
-                    if (i < qcount && tri_solve_ref(geom, nref, qfirst + i, q, a, b, t) && (!lfound || lt > t)) {
-                        lt = t; la = a; lb = b; lref = qfirst + i; lfound = true;
-                    }
+                    const bool counted = i < qcount && !(S.tri_prim[qfirst + (i < qcount ? i : 0)] & NO_SHADOW_BIT);
+                    tests += (uint32_t)__popcll(__ballot(counted));
                 }
-                unsigned long long cand = __ballot(lfound);
-                if (cand) {
-                    // lexicographic minimum of (t, leaf position) over the lanes that found a hit
-                    int l = first_lane(cand);
-                    for (;;) {
-                        const double tl = bcast_d(lt, l);
-                        const int32_t rl = bcast_i(lref, l);
-                        cand = __ballot(lfound && (lt < tl || (lt == tl && lref < rl)));
-                        if (!cand) break;
-                        l = first_lane(cand);
-                    }
-                    const double wt = bcast_d(lt, l), wa = bcast_d(la, l), wb = bcast_d(lb, l);
-                    const int32_t wr = bcast_i(lref, l);
-                    if (lane == src) { best.t = wt; best.alpha = wa; best.beta = wb; best.ref = wr; found = true; }
-                }
-                if (lane == src) w.tri((uint32_t)qcount);
             }
+            if (lane == src) w.tri(SHADOW ? tests : (uint32_t)qcount);
         }
 
         if (walking) {

@@ -15,7 +15,17 @@ using namespace rt;
 namespace {
 
 enum { MODE_PIXELS = 0, MODE_RAYS = 1, MODE_TILES = 2 };
-constexpr int BLOCK = 256;
+// One wave per workgroup: waves are independent (no LDS exchange, no barrier in the trace),
+// and single-wave groups let the dispatcher refill a SIMD as soon as a long wave retires.
+// RT_MIN_WAVES = 4 holds the kernel to 128 VGPRs (4 waves per SIMD); measured on the 1080p
+// dragon frame: 2 waves/SIMD 575, 3 -> 636, 4 -> 757, 5 -> 656 (spills) Mrays/s.
+#ifndef RT_BLOCK
+#define RT_BLOCK 64
+#endif
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 4
+#endif
+constexpr int BLOCK = RT_BLOCK;
 
 struct LaunchArgs {
     rtamd_camera cam;
@@ -52,7 +62,7 @@ __device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point,
 }
 
 template <int MODE, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
+__global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     bool live = k < A.n;
     Work<COUNT> work;

@@ -1,0 +1,83 @@
+"""Device-side arrangement of the flat scene tables.
+
+`flatten.flatten_world` yields the tables in the reference's own order: every kd leaf
+lists its triangles in the order `KDTree.hit` / `shadow_hit` scan them
+(/root/reference/kdtree.py:157-174).  That order is observable - ties in `t` go to the
+earlier item and a shadow query reports the first item that hits - but nothing says the
+items must be *stored* in it.  For leaves with more than one 64-triangle chunk this
+module
+
+  * stores the leaf's triangles in Morton order of their centroids, so that 64
+    consecutive rows are spatially compact,
+  * records each row's position in the reference order (`tri_order`), which the kernels
+    use for every tie-break and first-in-order decision, and
+  * gives every 64-row chunk an axis-aligned bounding box (`chunk_boxes`, padded), so a
+    wave can skip chunks a ray's line cannot touch.
+
+The degenerate leaves of the reference's build (hundreds to 1340 triangles, a few per
+mesh, visited by most rays) are where almost all triangle tests are spent; skipping
+chunks there changes no result, because a triangle the exact test accepts has its hit
+point inside its own (padded) bounding box.
+"""
+import ctypes as C
+
+import numpy
+
+from . import capi
+
+CHUNK = 64
+PAD = 1.0e-9
+
+
+def _morton_order(centroids):
+    lo = centroids.min(axis=0)
+    span = numpy.maximum(centroids.max(axis=0) - lo, 1e-300)
+    q = numpy.minimum(((centroids - lo) / span * 1024.0).astype(numpy.int64), 1023)
+    code = numpy.zeros(len(centroids), dtype=numpy.int64)
+    for bit in range(10):
+        for axis in range(3):
+            code |= ((q[:, axis] >> bit) & 1) << (3 * bit + axis)
+    return numpy.argsort(code, kind="stable")
+
+
+def device_arrays(flat):
+    """Tables to upload: the canonical ones, with big leaves re-arranged, plus
+    `tri_order` (int32 per row) and `chunk_boxes` (SoA [6][n_chunks]: lo xyz, hi xyz)."""
+    a = dict(flat.arrays)
+    n_refs = len(a["tri_prim"])
+    geom = a["tri_geom"].reshape(9, n_refs).copy() if n_refs else numpy.zeros((9, 0))
+    prim = a["tri_prim"].copy()
+    order = numpy.arange(n_refs, dtype=numpy.int32)
+    nodes = a["kd_nodes"].view([("split", "<f8"), ("a", "<i4"), ("b", "<i4")]).copy()
+    boxes_lo, boxes_hi = [], []
+    n_chunks = 0
+    leaves = numpy.nonzero((nodes["b"] & 3) == 3)[0]
+    counts = nodes["b"][leaves] >> 2
+    nodes["split"][leaves] = -1.0
+    for node, count in zip(leaves[counts > CHUNK], counts[counts > CHUNK]):
+        first = int(nodes["a"][node])
+        rows = slice(first, first + int(count))
+        g = geom[:, rows]
+        v0, v1, v2 = g[0:3].T, (g[0:3] + g[3:6]).T, (g[0:3] + g[6:9]).T
+        perm = _morton_order((v0 + v1 + v2) / 3.0)
+        geom[:, rows] = g[:, perm]
+        prim[rows] = prim[rows][perm]
+        order[rows] = first + perm.astype(numpy.int32)
+        lo = numpy.minimum(numpy.minimum(v0, v1), v2)[perm]
+        hi = numpy.maximum(numpy.maximum(v0, v1), v2)[perm]
+        nodes["split"][node] = float(n_chunks)
+        for c in range(0, int(count), CHUNK):
+            blo, bhi = lo[c:c + CHUNK].min(axis=0), hi[c:c + CHUNK].max(axis=0)
+            boxes_lo.append(blo - PAD * (1.0 + numpy.abs(blo)))
+            boxes_hi.append(bhi + PAD * (1.0 + numpy.abs(bhi)))
+            n_chunks += 1
+    if n_chunks:
+        chunk_boxes = numpy.ascontiguousarray(numpy.concatenate([numpy.array(boxes_lo).T, numpy.array(boxes_hi).T], axis=0))
+    else:
+        chunk_boxes = numpy.zeros((6, 0))
+    a["tri_geom"] = numpy.ascontiguousarray(geom).ravel()
+    a["tri_prim"] = prim
+    a["tri_order"] = order
+    a["chunk_boxes"] = chunk_boxes.ravel()
+    a["kd_nodes"] = nodes.view(numpy.uint8)
+    return a, n_chunks

@@ -11,7 +11,7 @@ import ctypes as C
 
 import numpy
 
-from . import capi, flatten, rng
+from . import capi, device_layout, flatten, rng
 
 
 def _torch():
@@ -43,12 +43,16 @@ class DeviceScene(object):
         self.flat = flatten.flatten_world(world)
         self.tensors = {}
         with torch.cuda.device(self.device):
-            for name, arr in self.flat.arrays.items():
+            arrays, n_chunks = device_layout.device_arrays(self.flat)
+            for name, arr in arrays.items():
                 host = torch.from_numpy(numpy.ascontiguousarray(arr).view(numpy.uint8).reshape(-1).copy())
                 if host.numel() == 0:
                     host = torch.zeros(16, dtype=torch.uint8)
                 self.tensors[name] = host.to(self.device)
             desc = self.flat.desc(lambda name, arr: self.tensors[name].data_ptr())
+            desc.tri_order = self.tensors["tri_order"].data_ptr()
+            desc.chunk_boxes = self.tensors["chunk_boxes"].data_ptr()
+            desc.n_chunks = n_chunks
             handle = C.c_void_p()
             capi.check(self.lib.rtamd_scene_create(C.byref(desc), C.byref(handle)), self.lib)
         self.handle = handle
