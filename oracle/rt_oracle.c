@@ -358,7 +358,6 @@ static int object_hit(ctx_t *c, int idx, const ray_t *world_ray, hit_t *h) {
     case RTAMD_TRIANGLE: {
         double g[9], a, b;
         bare_triangle(p, g);
-        c->w.tris++;
         hit = tri_test(g, 1, r, &a, &b, &t);
         if (hit) {
             if (ob->smooth) n = add(add(scl(P3(p + 12), 1 - a - b), scl(P3(p + 15), a)), scl(P3(p + 18), b));
@@ -439,7 +438,6 @@ static int object_shadow(ctx_t *c, int idx, const ray_t *world_ray, double *t) {
     case RTAMD_TRIANGLE: {
         double g[9], a, b;
         bare_triangle(p, g);
-        c->w.tris++;
         return tri_test(g, 1, r, &a, &b, t);
     }
     default: return 0;

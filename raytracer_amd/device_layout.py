@@ -57,7 +57,7 @@ def device_arrays(flat):
     for node, count in zip(leaves[counts > CHUNK], counts[counts > CHUNK]):
         first = int(nodes["a"][node])
         rows = slice(first, first + int(count))
-        g = geom[:, rows]
+        g = geom[:, rows].copy()
         v0, v1, v2 = g[0:3].T, (g[0:3] + g[3:6]).T, (g[0:3] + g[6:9]).T
         perm = _morton_order((v0 + v1 + v2) / 3.0)
         geom[:, rows] = g[:, perm]

@@ -37,6 +37,8 @@ def test_gpu_matches_reference_golden(torch_gpu, scene):
     ("features_mesh", 60, (0, 4)),
     ("features_env", 60, (2, 7)),
     ("dragon_area", 40, (0, 4)),
+    ("dragon_area", 420, (0, 16)),
+    ("j", 600, (0, 1)),
 ])
 def test_gpu_tiles_match_oracle(torch_gpu, scene, tiles, samples):
     """Whole tiles through rtamd_render_tiles (ray generation on the device) against the
@@ -56,8 +58,11 @@ def test_gpu_tiles_match_oracle(torch_gpu, scene, tiles, samples):
     n = len(tile_ids) * 64 * (s1 - s0)
     fb = runtime.FrameBuffers(ds, tile_ids)
     per = ds.sample_buffers(n)
-    ds.render_tiles(cam, world.seed, fb.tile_ids, s0, s1, sum_rgb8=fb.sum_rgb8, sum_sq=fb.sum_sq, per_sample=per)
+    ds.read_counters(reset=True)
+    ds.render_tiles(cam, world.seed, fb.tile_ids, s0, s1, sum_rgb8=fb.sum_rgb8, sum_sq=fb.sum_sq, per_sample=per,
+                    count_work=True)
     torch.cuda.synchronize()
+    gpu_work = ds.read_counters(reset=True)
     got = {k: v.cpu().numpy() for k, v in per[0].items()}
     osc = oracle.OracleScene(common.flat_for(scene))
     want_rgb8, want_sq, want = osc.render_tiles(cam, world.seed, tile_ids, s0, s1,
@@ -66,6 +71,9 @@ def test_gpu_tiles_match_oracle(torch_gpu, scene, tiles, samples):
     assert numpy.array_equal(got["hit_object"], want["hit_object"])
     assert numpy.array_equal(got["hit_prim"], want["hit_prim"])
     assert numpy.array_equal(got["n_rays"], want["n_rays"])
+    # the counting launch reports the work of the reference algorithm (kd steps, leaves,
+    # triangle and analytic tests), whatever shortcuts the kernel takes: identical to the oracle's
+    assert gpu_work == osc.read_counters(reset=True)
     close, worst = common.rgb_close(got["rgb"], want["rgb"])
     assert close, "worst relative error %g" % worst
     # int(c*255) of one sample may differ by one only where c*255 is within rounding of an
@@ -79,6 +87,11 @@ def test_gpu_tiles_match_oracle(torch_gpu, scene, tiles, samples):
     d = numpy.abs(fb.sum_rgb8.cpu().numpy() - want_rgb8)
     assert (d <= edge_per_pixel).all(), "integer accumulators differ beyond rounding knife-edges"
     assert numpy.allclose(fb.sum_sq.cpu().numpy(), want_sq, rtol=1e-8, atol=1e-12)
+    # the timed (non-counting) kernel variant gives the same frame
+    fb2 = runtime.FrameBuffers(ds, tile_ids)
+    ds.render_tiles(cam, world.seed, fb2.tile_ids, s0, s1, sum_rgb8=fb2.sum_rgb8)
+    torch.cuda.synchronize()
+    assert torch.equal(fb2.sum_rgb8, fb.sum_rgb8)
     print("%s: %d samples, worst relative radiance error vs oracle %.3g, accumulator mismatches %d"
           % (scene, n, worst, int((d > 0).sum())))
 
