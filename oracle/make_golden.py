@@ -325,11 +325,15 @@ def render_mode_golden(harness):
     world = harness.build("cornellbox_area", "parallel", dict(resolution=(8, 6), sample_dim=2))
     vp = world.viewplane
     w = vp.resolution[0]
-    state = dict(pixel=-1, sample=0)
+    state = dict(pixel=-1, sample=0, tracing=False)
     orig_sample = vp.sampler.sample
     orig_trace = world.tracer.trace_ray
 
     def sample():
+        # the area light draws from this same sampler object while a ray is being traced
+        # (geometry.py:379 / the scene's quad emitter); only the camera's call opens a pixel
+        if state["tracing"]:
+            return orig_sample()
         state["pixel"] += 1
         state["sample"] = 0
         rng.context.point(rng.PHASE_PIXEL, state["pixel"], 0, 0)
@@ -339,7 +343,11 @@ def render_mode_golden(harness):
         if depth == 0:
             rng.context.point(rng.PHASE_TRACE, state["pixel"], state["sample"], 0)
             state["sample"] += 1
-        return orig_trace(ray, depth)
+        state["tracing"] = True
+        try:
+            return orig_trace(ray, depth)
+        finally:
+            state["tracing"] = depth != 0
     vp.sampler.sample = sample
     world.tracer.trace_ray = trace_ray
     got = []

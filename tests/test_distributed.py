@@ -1,0 +1,100 @@
+"""Frame partition over ranks and the gather to rank 0, on CPU with the gloo backend
+(world_size 2 and 3).  The per-rank renderer is injected: here it is the CPU checker, on
+the GPU box the default is the HIP tile kernel; partition, padding, gather and assembly
+are the code under test."""
+import os
+import socket
+
+import numpy
+import pytest
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world_size, port, scene, overrides, out_path):
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from raytracer_amd.world import World
+    from raytracer_amd import distributed, flatten
+    from oracle import oracle
+    world = World.__new__(World)
+    world.overrides = overrides
+    World.__init__(world, viewmode="parallel", buildfunction=scene, seed=3)
+    osc = oracle.OracleScene(flatten.flatten_world(world))
+    cam = flatten.camera_record(world)
+    n_samples = len(world.viewplane.sampler.patterns[0])
+
+    def render_fn(tile_ids, sum_rgb8, sum_sq):
+        a, b, _ = osc.render_tiles(cam, world.seed, tile_ids.numpy(), 0, n_samples, threads=2)
+        if sum_rgb8 is not None:
+            sum_rgb8[:len(a)] += torch.from_numpy(a)
+        if sum_sq is not None:
+            sum_sq[:len(b)] += torch.from_numpy(b)
+
+    for mode in ("parallel", "render"):
+        job = distributed.FrameJob(world, rank, world_size, render_fn=render_fn, mode=mode)
+        parts = job.render()
+        frame = job.finish(parts)
+        if rank == 0:
+            numpy.save(out_path + "." + mode + ".npy", frame)
+        else:
+            assert frame is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size", (2, 3))
+def test_frame_over_ranks_equals_single_rank(tmp_path, world_size):
+    import torch.multiprocessing as mp
+    scene, overrides = "cornellbox_area", dict(resolution=(44, 30), sample_dim=2)   # partial edge tiles
+    out = str(tmp_path / "frame")
+    mp.spawn(_worker, args=(world_size, _free_port(), scene, overrides, out), nprocs=world_size, join=True)
+    single = str(tmp_path / "single")
+    _worker_single(scene, overrides, single)
+    for mode in ("parallel", "render"):
+        a = numpy.load(out + "." + mode + ".npy")
+        b = numpy.load(single + "." + mode + ".npy")
+        assert a.shape == (30, 44, 3) and numpy.array_equal(a, b)
+        assert a.max() > 0
+
+
+def _worker_single(scene, overrides, out_path):
+    from raytracer_amd.world import World
+    from raytracer_amd import distributed, flatten, runtime
+    from oracle import oracle
+    world = World.__new__(World)
+    world.overrides = overrides
+    World.__init__(world, viewmode="parallel", buildfunction=scene, seed=3)
+    osc = oracle.OracleScene(flatten.flatten_world(world))
+    cam = flatten.camera_record(world)
+    n_samples = len(world.viewplane.sampler.patterns[0])
+    tx, ty = runtime.tile_grid(cam.width, cam.height)
+    tiles = numpy.arange(tx * ty, dtype=numpy.int32)
+    a, b, _ = osc.render_tiles(cam, world.seed, tiles, 0, n_samples, threads=2)
+    par = numpy.minimum(runtime.scatter_tiles(a, tiles, cam.width, cam.height) / float(n_samples), 255)
+    ren = numpy.minimum(numpy.trunc(runtime.scatter_tiles(b, tiles, cam.width, cam.height) / float(n_samples) * 255), 255)
+    numpy.save(out_path + ".parallel.npy", numpy.clip(par, 0, 255).astype(numpy.uint8))
+    numpy.save(out_path + ".render.npy", numpy.clip(ren, 0, 255).astype(numpy.uint8))
+
+
+def test_partition_covers_every_tile_once():
+    from raytracer_amd import distributed, runtime
+    for (w, h) in ((1920, 1080), (44, 30), (8, 8)):
+        tx, ty = runtime.tile_grid(w, h)
+        for world_size in (1, 2, 3, 4, 8):
+            parts = [distributed.tiles_of_rank(w, h, r, world_size) for r in range(world_size)]
+            allt = numpy.sort(numpy.concatenate(parts))
+            assert numpy.array_equal(allt, numpy.arange(tx * ty))
+            sizes = [len(p) for p in parts]
+            assert max(sizes) == distributed.padded_tile_count(w, h, world_size)
+            if tx * ty >= 8 * world_size:
+                assert max(sizes) - min(sizes) <= max(2, tx * ty // (world_size * 20))   # balanced

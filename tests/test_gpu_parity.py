@@ -124,3 +124,68 @@ def test_empty_and_error_paths(torch_gpu):
     bad = capi.Camera()
     assert lib.rtamd_render_pixels(ds.handle, C.byref(bad), 1, 1, None, None, None, None, None, None, 0, None) != 0
     assert b"view plane" in lib.rtamd_last_error()
+
+
+def _tiny_world(scene, resolution=(8, 6), sample_dim=2, seed=1):
+    from raytracer_amd.world import World
+    world = World.__new__(World)
+    world.overrides = dict(resolution=resolution, sample_dim=sample_dim)
+    World.__init__(world, viewmode="parallel", buildfunction=scene, seed=seed)
+    return world
+
+
+def test_camera_render_matches_reference(torch_gpu):
+    """camera.render (mean of squared radiance, camera.py:35-58): the integer triples handed
+    to pixel_func equal the reference's on the 8x6 golden frame; render_progressive ends on
+    the same frame after reporting every pixel once per sample pass."""
+    g = common.golden("frame_order")["render_pixels"]
+    world = _tiny_world("cornellbox_area")
+    got = []
+    world.camera.render(world, lambda coord, r, g_, b: got.append((coord[0], coord[1], r, g_, b)))
+    got = numpy.array(got, dtype=numpy.int64)
+    assert numpy.array_equal(got[:, :2], g[:, :2])                   # row-major pixel order
+    d = numpy.abs(got[:, 2:] - g[:, 2:])
+    assert d.max() <= 1 and (d > 0).mean() < 0.02
+    prog = []
+    world.camera.render_progressive(world, lambda coord, r, g_, b: prog.append((coord[0], coord[1], r, g_, b)))
+    prog = numpy.array(prog, dtype=numpy.int64)
+    assert len(prog) == 4 * len(got)                                   # one report per pixel per pass
+    assert numpy.abs(prog[-len(got):, 2:] - got[:, 2:]).max() <= 1
+
+
+@pytest.mark.parametrize("scene", ("cornellbox_area", "mirrorhall_dof"))
+def test_render_pixels_seam_reproduces_the_frame(torch_gpu, scene):
+    """The worker loop of main.py:86-90 over the producer's chunks, averaged like
+    main.py:99-106, gives the same image as the whole-frame tile kernel."""
+    world = _tiny_world(scene, resolution=(24, 16), sample_dim=2, seed=5)
+    sums = {}
+    n_pairs = 0
+    for chunk in world.camera.get_pixel_plane_point_pairs(world, 100):
+        for pixel, r, g, b in world.camera.render_pixels(world, chunk):
+            acc = sums.setdefault(tuple(pixel), numpy.zeros(4))
+            acc += (r, g, b, 1)
+            n_pairs += 1
+    assert n_pairs == 24 * 16 * 4
+    image = world.render(mode="parallel")
+    for (col, row), acc in sums.items():
+        mean = numpy.minimum(acc[:3] / acc[3], 255)
+        assert numpy.array_equal(mean.astype(numpy.uint8), image[row, col])
+
+
+def test_tracer_and_world_methods(torch_gpu):
+    """world.tracer.trace_ray and world.hit_objects answer single rays from the host."""
+    import tracer
+    world = common.world_for("foursphere")
+    g = common.golden("foursphere")
+    k = int(numpy.nonzero(g["hit_object"] >= 0)[0][0])
+    ray = tracer.Ray(g["origin"][k], g["direction"][k])
+    from raytracer_amd import rng
+    width = world.viewplane.resolution[0]
+    rng.context.point(rng.PHASE_TRACE, int(g["pixel"][k, 1]) * width + int(g["pixel"][k, 0]), int(g["sample"][k]))
+    rgb = world.tracer.trace_ray(ray)
+    assert common.rgb_close(numpy.array(rgb), g["rgb"][k])[0]
+    rec = world.hit_objects(ray)
+    assert rec.object_index == g["hit_object"][k] and abs(rec.tmin - g["hit_t"][k]) < 1e-9 * g["hit_t"][k]
+    miss = tracer.Ray((0., 50., 0.), (0., 1., 0.))
+    assert world.hit_objects(miss) is None
+    assert tuple(world.tracer.trace_ray(miss)) == tuple(world.background_color)
