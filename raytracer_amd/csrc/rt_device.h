@@ -190,6 +190,96 @@ __device__ __forceinline__ bool root_box(const rtamd_tree& T, const Ray& r, doub
 
 struct TriHit { double t, alpha, beta; int32_t ref; };
 
+// Leaves of at most W rows (W = 16 or 32), 64/W rays per step: the wave is split into
+// groups of W lanes, each group takes the ray of one pending lane (ds_bpermute), tests
+// that lane's leaf with one row per group lane and reduces inside the group; the pending
+// lane then collects its group's result.  Rows of such leaves are stored in scan order,
+// so the scan position of a row is its lane's position in the group.
+template <bool COUNT, bool SHADOW, int W>
+__device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, unsigned long long pending, const Ray& r,
+                                              int32_t first, int32_t count, Work<COUNT>& w, bool& found,
+                                              TriHit& best) {
+    constexpr int R = 64 / W;
+    const int lane = lane_id();
+    const int grp = lane / W, sub = lane % W;
+    const int64_t nref = S.n_refs;
+    const double* __restrict__ geom = S.tri_geom;
+    while (pending) {
+        int owner = -1, my_group = -1;
+#pragma unroll
+        for (int g = 0; g < R; ++g) {
+            if (pending) {
+                const int o = first_lane(pending);
+                pending &= pending - 1;
+                if (g == grp) owner = o;
+                if (o == lane) my_group = g;
+            }
+        }
+        const int src = owner < 0 ? lane : owner;
+        Ray q;
+        q.o = v3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
+        q.d = v3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
+        const int32_t qfirst = __shfl(first, src);
+        const int32_t src_count = __shfl(count, src);     // unconditional: every lane must take part
+        const int32_t qcount = owner < 0 ? 0 : src_count;
+        const bool in = sub < qcount;
+        const int32_t ref = qfirst + (in ? sub : 0);
+        bool usable = in;
+        if (SHADOW) usable = in && !(S.tri_prim[ref] & NO_SHADOW_BIT);                    // geometry.py:433-434
+        double a = 0, b = 0, t = 0;
+        const bool hit = usable && tri_solve_ref(geom, nref, ref, q, a, b, t);
+        const unsigned long long hm = __ballot(hit);
+        const unsigned long long group_mask = (W == 32) ? 0xffffffffull : 0xffffull;
+        bool g_found = false;
+        double g_t = 0, g_a = 0, g_b = 0;
+        int g_sub = 0;
+        if (hm) {
+            if (SHADOW) {
+                const uint32_t gb = (uint32_t)((hm >> (grp * W)) & group_mask);
+                g_found = gb != 0;
+                g_sub = g_found ? (int)__builtin_ctz(gb) : 0;
+                g_t = __shfl(t, grp * W + g_sub);
+            } else {
+                double bt = hit ? t : T_INF * 4.0;
+                int bs = sub;
+                for (int off = W / 2; off > 0; off >>= 1) {
+                    const double ot = __shfl_xor(bt, off);
+                    const int os = __shfl_xor(bs, off);
+                    const bool take = ot < bt || (ot == bt && os < bs);
+                    bt = take ? ot : bt;
+                    bs = take ? os : bs;
+                }
+                g_found = bt < T_INF * 4.0;
+                g_sub = bs;
+                g_t = bt;
+                g_a = __shfl(a, grp * W + bs);
+                g_b = __shfl(b, grp * W + bs);
+            }
+        }
+        uint32_t g_tests = 0;
+        if (COUNT && SHADOW) {
+            const uint32_t ub = (uint32_t)((__ballot(usable) >> (grp * W)) & group_mask);
+            g_tests = g_found ? (uint32_t)__popc(ub & ((2u << g_sub) - 1u)) : (uint32_t)__popc(ub);
+        }
+        // hand the group results to the lanes that own the rays
+        const int from = (my_group < 0 ? 0 : my_group) * W;
+        if (COUNT) {
+            const uint32_t n = SHADOW ? (uint32_t)__shfl((int)g_tests, from) : (uint32_t)count;
+            if (my_group >= 0) w.tri(n);
+        }
+        if (hm) {
+            const int o_found = __shfl((int)g_found, from);
+            const double o_t = __shfl(g_t, from);
+            const int o_sub = __shfl(g_sub, from);
+            double o_a = 0, o_b = 0;
+            if (!SHADOW) { o_a = __shfl(g_a, from); o_b = __shfl(g_b, from); }
+            if (my_group >= 0 && o_found) {
+                best.t = o_t; best.alpha = o_a; best.beta = o_b; best.ref = first + o_sub; found = true;
+            }
+        }
+    }
+}
+
 // One kd-tree query per active lane, all 64 lanes inside.
 //
 // Each lane walks the tree front to back exactly as KDTree.iterate_nodes does
@@ -264,7 +354,14 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
             }
         }
 
-        unsigned long long big = __ballot(walking && !small);
+        // leaves of up to 16 / 32 rows: four / two rays per step
+        const bool pack16 = walking && !small && count <= 16;
+        const bool pack32 = walking && !small && !pack16 && count <= 32;
+        const unsigned long long p16 = __ballot(pack16), p32 = __ballot(pack32);
+        if (p16) packed_leaves<COUNT, SHADOW, 16>(S, p16, r, first, count, w, found, best);
+        if (p32) packed_leaves<COUNT, SHADOW, 32>(S, p32, r, first, count, w, found, best);
+
+        unsigned long long big = __ballot(walking && !small && count > 32);
         while (big) {
             const int src = first_lane(big);
             big &= big - 1;
