@@ -42,7 +42,13 @@ def gather_to_root(local, dist=None, root=0):
     world = dist.get_world_size()
     rank = dist.get_rank()
     parts = [torch.empty_like(local) for _ in range(world)] if rank == root else None
-    dist.gather(local, gather_list=parts, dst=root)
+    try:
+        dist.gather(local, gather_list=parts, dst=root)
+    except (RuntimeError, NotImplementedError):
+        # a backend without gather: all ranks collect, only the root keeps the result
+        every = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(every, local)
+        parts = every if rank == root else None
     return parts
 
 
