@@ -169,7 +169,17 @@ __device__ __forceinline__ bool tri_solve_ref(const double* __restrict__ g, int6
 }
 
 // ---------------------------------------------------------------- kd-tree
-struct KdStackEntry { int32_t node; double t_near, t_far; };
+// Traversal stack of one wave.  An entry is (far child, t at the split plane); the far
+// bound that kdtree.py:152 pushes along with them is always the t of the entry below (or
+// the root box's exit distance for the bottom entry), so it is recovered on pop instead
+// of being stored.  The first LDS_STACK entries of every lane live in LDS, lane-
+// interleaved (conflict-free); deeper entries go to per-lane private memory.
+constexpr int LDS_STACK = 10;
+struct KdStack {
+    int32_t* node;      // LDS, [LDS_STACK][64]
+    double* t;          // LDS, [LDS_STACK][64]
+};
+#define RT_KD_STACK_LDS_BYTES (LDS_STACK * 64 * 12)
 #ifndef RT_SMALL_LEAF
 #define RT_SMALL_LEAF 0
 #endif
@@ -293,11 +303,13 @@ __device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, unsigne
 // leaf order that reports a hit ends the query and its t is returned.
 template <bool COUNT, bool SHADOW>
 __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool active, const Ray& r,
-                              Work<COUNT>& w, bool& found, TriHit& best) {
+                              const KdStack& stk, Work<COUNT>& w, bool& found, TriHit& best) {
     found = false;
-    double t_near = 0, t_far = 0;
-    bool walking = active && root_box(T, r, t_near, t_far);
-    KdStackEntry stack[STACK_MAX];
+    double t_near = 0, t_far = 0, t_exit = 0;
+    bool walking = active && root_box(T, r, t_near, t_exit);
+    t_far = t_exit;
+    int32_t deep_node[STACK_MAX - LDS_STACK];       // only touched by trees deeper than LDS_STACK
+    double deep_t[STACK_MAX - LDS_STACK];
     int sp = 0;
     int32_t node = T.node_offset;
     const int lane = lane_id();
@@ -321,7 +333,8 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 } else if (t <= t_near) {
                     node = far_n;
                 } else {
-                    stack[sp].node = far_n; stack[sp].t_near = t; stack[sp].t_far = t_far;
+                    if (sp < LDS_STACK) { stk.node[sp * 64 + lane] = far_n; stk.t[sp * 64 + lane] = t; }
+                    else { deep_node[sp - LDS_STACK] = far_n; deep_t[sp - LDS_STACK] = t; }
                     sp++;
                     node = near_n;
                     t_far = t;
@@ -478,7 +491,12 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 walking = false;
             } else {
                 sp--;
-                node = stack[sp].node; t_near = stack[sp].t_near; t_far = stack[sp].t_far;
+                if (sp < LDS_STACK) { node = stk.node[sp * 64 + lane]; t_near = stk.t[sp * 64 + lane]; }
+                else { node = deep_node[sp - LDS_STACK]; t_near = deep_t[sp - LDS_STACK]; }
+                // the far bound pushed with this entry = t of the entry now on top, or the root exit
+                if (sp == 0) t_far = t_exit;
+                else if (sp - 1 < LDS_STACK) t_far = stk.t[(sp - 1) * 64 + lane];
+                else t_far = deep_t[sp - 1 - LDS_STACK];
             }
         }
     }
@@ -593,7 +611,8 @@ struct Hit {
 
 // World.hit_objects (main.py:35-46) for every active lane: objects in list order, strict `<`.
 template <bool COUNT>
-__device__ bool closest_hit_wave(const rtamd_scene_desc& S, bool active, const Ray& ray, Work<COUNT>& w, Hit& h) {
+__device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, bool active, const Ray& ray,
+                                 Work<COUNT>& w, Hit& h) {
     if (active) w.closest++;
     double tmin = T_INF;
     bool any = false;
@@ -610,7 +629,7 @@ __device__ bool closest_hit_wave(const rtamd_scene_desc& S, bool active, const R
                 const rtamd_tree& T = S.trees[ob.tree];
                 TriHit th;
                 bool f;
-                kd_query_wave<COUNT, false>(S, T, active, r, w, f, th);
+                kd_query_wave<COUNT, false>(S, T, active, r, stk, w, f, th);
                 if (active && f) {
                     hit = true;
                     t = th.t;
@@ -678,8 +697,8 @@ __device__ bool closest_hit_wave(const rtamd_scene_desc& S, bool active, const R
 // light.in_shadow for every lane with `need`: any object that reports a hit [closer than
 // `limit`] (light.py:31-37 / :124-130 with a distance, :60-65 / :78-83 / :170-175 without).
 template <bool COUNT>
-__device__ bool occluded_wave(const rtamd_scene_desc& S, bool need, const Ray& ray, bool use_limit, double limit,
-                              Work<COUNT>& w) {
+__device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, bool need, const Ray& ray,
+                              bool use_limit, double limit, Work<COUNT>& w) {
     if (need) w.shadow++;
     bool occ = false;
     for (int i = 0; i < S.n_objects; ++i) {
@@ -693,7 +712,7 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, bool need, const Ray& r
             if (__ballot(q)) {
                 TriHit th;
                 bool f;
-                kd_query_wave<COUNT, true>(S, S.trees[ob.tree], q, r, w, f, th);
+                kd_query_wave<COUNT, true>(S, S.trees[ob.tree], q, r, stk, w, f, th);
                 hit = q && f;
                 t = th.t;
             }
@@ -742,8 +761,8 @@ __device__ __forceinline__ V3 phong_lobe(V3 spec, double exp_, V3 n, V3 wo, V3 w
 // :346-377) for every lane with `lit`; `area` selects the G/pdf weighting.  Lights are
 // visited in list order by the whole wave so that the shadow queries stay wave-wide.
 template <bool COUNT>
-__device__ V3 direct_light_wave(const rtamd_scene_desc& S, bool lit, const rtamd_material& m, const Hit& h, V3 wo,
-                                bool area, Draw& dr, Work<COUNT>& w) {
+__device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, bool lit, const rtamd_material& m,
+                                const Hit& h, V3 wo, bool area, Draw& dr, Work<COUNT>& w) {
     // ambient_color.L(sr): AmbientLight (light.py:14-15) or AmbientOccluder (light.py:85-100)
     V3 amb = ld3(S.ambient.radiance);
     if (S.ambient.kind == RTAMD_AMBIENT_OCCLUDER) {
@@ -751,7 +770,7 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, bool lit, const rtamd
         sr.o = h.p;
         sr.d = v3(0, 0, 1);
         if (lit) sr.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
-        if (occluded_wave<COUNT>(S, lit, sr, false, 0.0, w)) amb = ld3(S.ambient.occluded);
+        if (occluded_wave<COUNT>(S, stk, lit, sr, false, 0.0, w)) amb = ld3(S.ambient.occluded);
     }
     V3 L = ld3(m.ambient) * amb;
     const bool phong = m.kind != RTAMD_MATTE;
@@ -792,7 +811,7 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, bool lit, const rtamd
             if (lt.kind == RTAMD_POINT) limit = norm(sr.o - ld3(lt.position));                    // light.py:32
             else if (lt.kind == RTAMD_AREA) limit = dot(sample_point - sr.o, sr.d);               // light.py:125
             const bool bounded = lt.kind == RTAMD_POINT || lt.kind == RTAMD_AREA;
-            if (__ballot(facing)) in_shadow = occluded_wave<COUNT>(S, facing, sr, bounded, limit, w);
+            if (__ballot(facing)) in_shadow = occluded_wave<COUNT>(S, stk, facing, sr, bounded, limit, w);
         }
         if (!facing || in_shadow || !gate) continue;
         V3 f = ld3(m.diffuse);
@@ -826,8 +845,8 @@ struct Primary { int32_t object, prim; double t; };
 // (product of the child weights so far) * local term.  Lanes whose path has ended stay in
 // the loop as helpers for the wave-wide kd leaf tests until every lane is done.
 template <bool COUNT>
-__device__ V3 trace_wave(const rtamd_scene_desc& S, bool alive, Ray ray, int depth, Draw& dr, Work<COUNT>& w,
-                         Primary& first) {
+__device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
+                         Work<COUNT>& w, Primary& first) {
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
     const V3 background = (S.tracer_kind == RTAMD_TRACER_SHADE) ? ld3(S.background) : v3(0, 0, 0);
     const bool area = S.tracer_kind == RTAMD_TRACER_AREA;
@@ -838,7 +857,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, bool alive, Ray ray, int dep
         if (!__ballot(alive)) break;
         Hit h;
         h.p = v3(0, 0, 0); h.n = v3(0, 0, 1); h.material = 0;
-        const bool hit = closest_hit_wave<COUNT>(S, alive, ray, w, h);
+        const bool hit = closest_hit_wave<COUNT>(S, stk, alive, ray, w, h);
         if (alive && !hit) { L = L + W * background; alive = false; }
         if (alive && primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; }
         primary = false;
@@ -872,7 +891,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, bool alive, Ray ray, int dep
             continue;
         }
 
-        const V3 Ld = direct_light_wave<COUNT>(S, alive, m, h, wo, area, dr, w);
+        const V3 Ld = direct_light_wave<COUNT>(S, stk, alive, m, h, wo, area, dr, w);
         if (alive) L = L + W * Ld;
         if (area) { alive = false; continue; }
         if (!alive) continue;

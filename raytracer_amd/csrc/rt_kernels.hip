@@ -26,6 +26,7 @@ enum { MODE_PIXELS = 0, MODE_RAYS = 1, MODE_TILES = 2 };
 #define RT_MIN_WAVES 4
 #endif
 constexpr int BLOCK = RT_BLOCK;
+static_assert(BLOCK == 64, "the LDS traversal stack is sized for one wave per workgroup");
 
 struct LaunchArgs {
     rtamd_camera cam;
@@ -126,7 +127,13 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         dr.sample = (uint32_t)sample;
         dr.counter = 0;
         Primary first;
-        const V3 c = trace_wave<COUNT>(S, live, ray, A.depth0, dr, work, first);
+        // the wave's kd traversal stack (one wave per workgroup)
+        __shared__ double stack_t[LDS_STACK * 64];
+        __shared__ int32_t stack_node[LDS_STACK * 64];
+        KdStack stk;
+        stk.node = stack_node;
+        stk.t = stack_t;
+        const V3 c = trace_wave<COUNT>(S, stk, live, ray, A.depth0, dr, work, first);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
             if (A.out.rgb) { A.out.rgb[3 * k] = c.x; A.out.rgb[3 * k + 1] = c.y; A.out.rgb[3 * k + 2] = c.z; }
