@@ -22,6 +22,13 @@ enum { MODE_PIXELS = 0, MODE_RAYS = 1, MODE_TILES = 2 };
 #ifndef RT_BLOCK
 #define RT_BLOCK 64
 #endif
+#ifndef RT_XCD_SEGMENTS
+// XCD-aware work order (multiple of 8 segments; 0 = off).  Measured on the 1080p dragon
+// frame: off 30.8 ms, 8 segments 42.0 (XCDs unevenly loaded), 16 -> 31.6, 32 -> 31.8,
+// 64 -> 31.2.  The 24 MB scene is served from every L2 at 89 % hit rate either way and the
+// kernel is not bound by L2 misses, so the default is off.
+#define RT_XCD_SEGMENTS 0
+#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
@@ -39,6 +46,7 @@ struct LaunchArgs {
     const int32_t* tile_ids;
     int32_t depth0;
     int32_t sample_begin, n_samples, tiles_x;
+    int64_t seg_len;            // tile mode: waves per XCD segment, 0 = no remap
     rtamd_sample_out out;
     int64_t* sum_rgb8;
     double* sum_sq;
@@ -64,7 +72,17 @@ __device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point,
 
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
-    const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
+    // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
+    // work list is cut into RT_XCD_SEGMENTS contiguous segments and segment j is given to
+    // the workgroups of XCD j % 8, so each L2 serves a few bands of the frame instead of
+    // every tile; A.seg_len == 0 keeps the identity order.
+    int64_t wave = blockIdx.x;
+    if (MODE == MODE_TILES && A.seg_len > 0) {
+        const int64_t x = wave & 7, i = wave >> 3;
+        wave = ((i / A.seg_len) * 8 + x) * A.seg_len + (i % A.seg_len);
+    }
+    const int64_t k = wave * BLOCK + threadIdx.x;
     bool live = k < A.n;
     Work<COUNT> work;
     int64_t acc_row = -1;
@@ -189,9 +207,15 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 template <int MODE>
-int launch(const rtamd_scene_desc& S, const LaunchArgs& A, uint32_t flags, void* stream) {
+int launch(const rtamd_scene_desc& S, LaunchArgs& A, uint32_t flags, void* stream) {
     if (A.n <= 0) return RTAMD_OK;
-    const int64_t blocks = (A.n + BLOCK - 1) / BLOCK;
+    A.seg_len = 0;
+    if (MODE == MODE_TILES && RT_XCD_SEGMENTS > 0) {
+        const int64_t waves = (A.n + BLOCK - 1) / BLOCK;
+        if (waves >= 64 * RT_XCD_SEGMENTS) A.seg_len = (waves + RT_XCD_SEGMENTS - 1) / RT_XCD_SEGMENTS;
+    }
+    int64_t blocks = (A.n + BLOCK - 1) / BLOCK;
+    if (A.seg_len > 0) blocks = A.seg_len * RT_XCD_SEGMENTS;      // padded so the remap is a bijection
     if (blocks > 0x7fffffffLL) return fail(RTAMD_EINVAL, "too many samples for one launch%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (flags & RTAMD_COUNT_WORK)
