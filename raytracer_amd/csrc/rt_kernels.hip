@@ -210,12 +210,14 @@ template <int MODE>
 int launch(const rtamd_scene_desc& S, LaunchArgs& A, uint32_t flags, void* stream) {
     if (A.n <= 0) return RTAMD_OK;
     A.seg_len = 0;
-    if (MODE == MODE_TILES && RT_XCD_SEGMENTS > 0) {
+#if RT_XCD_SEGMENTS > 0
+    if (MODE == MODE_TILES) {
         const int64_t waves = (A.n + BLOCK - 1) / BLOCK;
         if (waves >= 64 * RT_XCD_SEGMENTS) A.seg_len = (waves + RT_XCD_SEGMENTS - 1) / RT_XCD_SEGMENTS;
     }
+#endif
     int64_t blocks = (A.n + BLOCK - 1) / BLOCK;
-    if (A.seg_len > 0) blocks = A.seg_len * RT_XCD_SEGMENTS;      // padded so the remap is a bijection
+    if (A.seg_len > 0) blocks = A.seg_len * (RT_XCD_SEGMENTS > 0 ? RT_XCD_SEGMENTS : 1);   // padded: the remap is a bijection
     if (blocks > 0x7fffffffLL) return fail(RTAMD_EINVAL, "too many samples for one launch%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (flags & RTAMD_COUNT_WORK)
