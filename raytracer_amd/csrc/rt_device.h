@@ -157,14 +157,32 @@ __device__ __forceinline__ bool tri_solve_v(V3 v0, V3 e1, V3 e2, const Ray& r,
 __device__ __forceinline__ bool tri_solve(const double* g, const Ray& r, double& alpha, double& beta, double& t) {
     return tri_solve_v(ld3(g), ld3(g + 3), ld3(g + 6), r, alpha, beta, t);
 }
-// leaf reference `ref` of the scene's struct-of-arrays triangle table: component c of
-// row `ref` is tri_geom[c*n_refs + ref], so 64 consecutive references are 9 coalesced loads
-__device__ __forceinline__ bool tri_solve_ref(const double* __restrict__ g, int64_t n, int64_t ref, const Ray& r,
+// The scene's struct-of-arrays triangle table seen through a buffer descriptor: component c
+// of row `ref` is tri_geom[c*n_refs + ref], so 64 consecutive rows are 9 coalesced loads.
+// With buffer loads the per-lane part of the address is one 32-bit byte offset (ref*8) and
+// the component's plane offset (c*n_refs*8) rides in a scalar register, which removes the
+// 64-bit address arithmetic of nine separate global loads; rows past the table read as 0.
+struct TriTable {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int32_t plane;              // bytes between two component planes = n_refs * 8
+};
+__device__ __forceinline__ TriTable tri_table(const rtamd_scene_desc& S) {
+    TriTable t;
+    t.plane = (int32_t)(S.n_refs * 8);
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(S.tri_geom), 0, (int32_t)(S.n_refs * 72), 0x00020000);
+    return t;
+}
+__device__ __forceinline__ double tri_component(const TriTable& tt, int32_t byte_offset, int c) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(tt.rsrc, byte_offset, c * tt.plane, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ bool tri_solve_ref(const TriTable& tt, int32_t ref, const Ray& r,
                                               double& alpha, double& beta, double& t) {
-    const double* p = g + ref;
-    const V3 v0 = v3(p[0], p[n], p[2 * n]);
-    const V3 e1 = v3(p[3 * n], p[4 * n], p[5 * n]);
-    const V3 e2 = v3(p[6 * n], p[7 * n], p[8 * n]);
+    const int32_t off = ref * 8;
+    const V3 v0 = v3(tri_component(tt, off, 0), tri_component(tt, off, 1), tri_component(tt, off, 2));
+    const V3 e1 = v3(tri_component(tt, off, 3), tri_component(tt, off, 4), tri_component(tt, off, 5));
+    const V3 e2 = v3(tri_component(tt, off, 6), tri_component(tt, off, 7), tri_component(tt, off, 8));
     return tri_solve_v(v0, e1, e2, r, alpha, beta, t);
 }
 
@@ -212,8 +230,7 @@ __device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, unsigne
     constexpr int R = 64 / W;
     const int lane = lane_id();
     const int grp = lane / W, sub = lane % W;
-    const int64_t nref = S.n_refs;
-    const double* __restrict__ geom = S.tri_geom;
+    const TriTable geom = tri_table(S);
     while (pending) {
         int owner = -1, my_group = -1;
 #pragma unroll
@@ -237,7 +254,7 @@ __device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, unsigne
         bool usable = in;
         if (SHADOW) usable = in && !(S.tri_prim[ref] & NO_SHADOW_BIT);                    // geometry.py:433-434
         double a = 0, b = 0, t = 0;
-        const bool hit = usable && tri_solve_ref(geom, nref, ref, q, a, b, t);
+        const bool hit = usable && tri_solve_ref(geom, ref, q, a, b, t);
         const unsigned long long hm = __ballot(hit);
         const unsigned long long group_mask = (1ull << W) - 1ull;
         bool g_found = false;
@@ -313,8 +330,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     int sp = 0;
     int32_t node = T.node_offset;
     const int lane = lane_id();
-    const int64_t nref = S.n_refs;
-    const double* __restrict__ geom = S.tri_geom;
+    const TriTable geom = tri_table(S);
 
     while (__ballot(walking)) {
         int32_t first = 0, count = 0, cbase = -1;
@@ -354,13 +370,13 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                     if (S.tri_prim[first + i] & NO_SHADOW_BIT) continue;         // geometry.py:433-434
                     w.tri(1);
                     double a, b, t;
-                    if (tri_solve_ref(geom, nref, first + i, r, a, b, t)) { best.t = t; found = true; break; }
+                    if (tri_solve_ref(geom, first + i, r, a, b, t)) { best.t = t; found = true; break; }
                 }
             } else {
                 w.tri((uint32_t)count);
                 for (int32_t i = 0; i < count; ++i) {
                     double a, b, t;
-                    if (tri_solve_ref(geom, nref, first + i, r, a, b, t) && (!found || best.t > t)) {
+                    if (tri_solve_ref(geom, first + i, r, a, b, t) && (!found || best.t > t)) {
                         best.t = t; best.alpha = a; best.beta = b; best.ref = first + i; found = true;
                     }
                 }
@@ -402,7 +418,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 bool usable = in;
                 if (SHADOW) usable = in && !(S.tri_prim[in ? ref : qfirst] & NO_SHADOW_BIT);   // geometry.py:433-434
                 double a, b, t;
-                if (usable && tri_solve_ref(geom, nref, ref, q, a, b, t)) {
+                if (usable && tri_solve_ref(geom, ref, q, a, b, t)) {
                     const int32_t ord = S.tri_order ? S.tri_order[ref] : ref;
                     const bool better = SHADOW ? (!lfound || ord < lord)
                                                : (!lfound || t < lt || (t == lt && ord < lord));
