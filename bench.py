@@ -65,11 +65,17 @@ def main():
     if world_size != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world_size, args.gpus))
+    # RTAMD_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks
+    backend = os.environ.get("RTAMD_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world_size)
 
     from raytracer_amd.world import World
     from raytracer_amd import distributed, flatten, runtime

@@ -4,7 +4,7 @@
  * TEST INFRASTRUCTURE.  This file is the checker the HIP path is compared against and the
  * "port" CPU baseline timed by bench.py; it is never linked into, imported by or called
  * from the product (raytracer_amd/).  Its parity with the reference is pinned by
- * tests/golden/*.npz, which oracle/make_golden.py produced by running the reference
+ * the .npz files of tests/golden, which oracle/make_golden.py produced by running the reference
  * itself (converted to Python 3 in a temp dir) on the same seeded samples.
  *
  * It follows the reference function by function (paths under /root/reference), keeps

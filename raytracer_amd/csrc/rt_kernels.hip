@@ -294,6 +294,44 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
             return fail(RTAMD_EINVAL, "a sampler table lies outside sampler_data%s");
         }
     }
+    // sampler references of materials and lights (small tables: checked on a host copy)
+    for (int i = 0; i < d->n_materials; ++i) {
+        rtamd_material m;
+        e = hipMemcpy(&m, d->materials + i, sizeof(m), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the material table"); }
+        const bool draws = m.kind == RTAMD_GLOSSY_REFLECTIVE || (d->tracer_kind == RTAMD_TRACER_PATH && m.kind == RTAMD_MATTE);
+        if (m.kind < RTAMD_MATTE || m.kind > RTAMD_EMISSIVE) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "unknown material kind%s"); }
+        if (d->tracer_kind == RTAMD_TRACER_PATH && m.kind != RTAMD_MATTE && m.kind != RTAMD_EMISSIVE) {
+            rtamd_scene_destroy(s);
+            return fail(RTAMD_EUNSUPPORTED, "the path tracer needs Matte or Emissive materials%s");
+        }
+        if (draws && (m.sampler < 0 || m.sampler >= d->n_samplers)) {
+            rtamd_scene_destroy(s);
+            return fail(RTAMD_EINVAL, "a material that samples a lobe has no sampler%s");
+        }
+    }
+    for (int i = 0; i < d->n_lights; ++i) {
+        rtamd_light l;
+        e = hipMemcpy(&l, d->lights + i, sizeof(l), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the light table"); }
+        if (l.kind < RTAMD_POINT || l.kind > RTAMD_ENVIRONMENT) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "unknown light kind%s"); }
+        if ((l.kind == RTAMD_AREA || l.kind == RTAMD_ENVIRONMENT) && (l.sampler < 0 || l.sampler >= d->n_samplers)) {
+            rtamd_scene_destroy(s);
+            return fail(RTAMD_EINVAL, "an area or environment light has no sampler%s");
+        }
+    }
+    for (int i = 0; i < d->n_objects; ++i) {
+        rtamd_object o;
+        e = hipMemcpy(&o, d->objects + i, sizeof(o), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the object table"); }
+        const bool tree = o.kind == RTAMD_KDTREE;
+        if (o.kind < RTAMD_SPHERE || o.kind > RTAMD_KDTREE || (tree && (o.tree < 0 || o.tree >= d->n_trees)) ||
+            (!tree && (o.material < 0 || o.material >= d->n_materials)) ||
+            (o.kind == RTAMD_CHECKER_PLANE && (o.alt_material < 0 || o.alt_material >= d->n_materials))) {
+            rtamd_scene_destroy(s);
+            return fail(RTAMD_EINVAL, "an object refers to a tree or material outside its table%s");
+        }
+    }
     for (int i = 0; i < d->n_trees; ++i) {
         rtamd_tree t;
         e = hipMemcpy(&t, d->trees + i, sizeof(t), hipMemcpyDeviceToHost);

@@ -41,6 +41,8 @@ def gather_to_root(local, dist=None, root=0):
         return [local]
     world = dist.get_world_size()
     rank = dist.get_rank()
+    if local.is_cuda and dist.get_backend() == "gloo":
+        local = local.cpu()             # gloo gathers host tensors (CPU tests, single-GPU rehearsals)
     parts = [torch.empty_like(local) for _ in range(world)] if rank == root else None
     try:
         dist.gather(local, gather_list=parts, dst=root)

@@ -317,10 +317,13 @@ def flatten_world(world):
     if "occluded" in amb:
         _fill(scene.ambient.occluded, amb["occluded"])
 
-    if scene.tracer_kind == capi.TRACER_PATH:
-        for m in fl.materials:
-            if m.kind not in (M.MATTE, M.EMISSIVE):
-                raise NotImplementedError("PathTracer needs path_shade, which only Matte and Emissive have")
+    for m in fl.materials:
+        if scene.tracer_kind == capi.TRACER_PATH and m.kind not in (M.MATTE, M.EMISSIVE):
+            raise NotImplementedError("PathTracer needs path_shade, which only Matte and Emissive have")
+        samples_lobe = m.kind == M.GLOSSY_REFLECTIVE or (scene.tracer_kind == capi.TRACER_PATH and m.kind == M.MATTE)
+        if samples_lobe and m.sampler < 0:
+            # the reference fails here too: `None.sample_unit_hemisphere_surface` (material.py:47, :110)
+            raise ValueError("a material that samples a direction was built without a sampler")
 
     sampler_recs, sampler_data = fl.sampler_tables()
 

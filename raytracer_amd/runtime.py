@@ -344,7 +344,8 @@ def render_frame(world, camera, pixel_func, progressive=False):
     def report(count):
         torch.cuda.synchronize(ds.device)
         mean = scatter_tiles(fb.sum_sq.cpu().numpy(), tile_ids, w, h) / float(count)
-        vals = mean * 255
+        # int() of NaN / infinity raises in the reference (camera.py:58); report such pixels as 0 / the int32 limits
+        vals = numpy.nan_to_num(mean * 255, nan=0.0, posinf=2147483647.0, neginf=-2147483648.0)
         for row in range(h):
             for col in range(w):
                 r, g, b = vals[row, col]
