@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 1
+#define RTAMD_ABI_VERSION 2
 
 enum {
     RTAMD_OK = 0,
@@ -54,7 +54,10 @@ enum {
 /* material kinds (material.py) */
 enum {
     RTAMD_MATTE = 0, RTAMD_PHONG = 1, RTAMD_REFLECTIVE = 2,
-    RTAMD_GLOSSY_REFLECTIVE = 3, RTAMD_EMISSIVE = 4
+    RTAMD_GLOSSY_REFLECTIVE = 3, RTAMD_EMISSIVE = 4,
+    RTAMD_TRANSPARENT = 5,   /* material.py:414-437: mirror child + refracted child    */
+    RTAMD_DIELECTRIC = 6     /* material.py:440-483: Fresnel-weighted children, colour
+                                filter cf^t over the child's path length               */
 };
 
 /* light kinds (light.py) */
@@ -62,7 +65,16 @@ enum { RTAMD_POINT = 0, RTAMD_DIRECTIONAL = 1, RTAMD_AREA = 2, RTAMD_ENVIRONMENT
 enum { RTAMD_AMBIENT_CONSTANT = 0, RTAMD_AMBIENT_OCCLUDER = 1 };
 
 /* tracer kinds (tracer.py:21-88) */
-enum { RTAMD_TRACER_SHADE = 0, RTAMD_TRACER_AREA = 1, RTAMD_TRACER_PATH = 2 };
+enum {
+    RTAMD_TRACER_SHADE = 0, RTAMD_TRACER_AREA = 1, RTAMD_TRACER_PATH = 2,
+    RTAMD_TRACER_WHITTED = 3 /* tracer.py:38-58: as SHADE, and reports the hit distance
+                                to the calling material (Dielectric needs it)          */
+};
+
+/* Transparent and Dielectric spawn two child rays per hit (material.py:428,436,473-474).
+ * The device keeps the not-yet-traced sibling of every level of one sample's ray tree in
+ * a per-sample list, so scenes holding such materials need depth_limit + 1 <= this. */
+#define RTAMD_MAX_BRANCH_LEVELS 8
 
 /* One entry of world.objects, in list order (main.py:35-46 scans them in that order and
  * the earlier object wins ties).  `p` holds the primitive's parameters:
@@ -103,7 +115,15 @@ typedef struct rtamd_material {
     double reflect[3];      /* kr*cd            material.py:74 / :121             */
     double reflect_exp;
     double emit[3];         /* ls*color         material.py:492-493               */
-    double pad_;
+    double kt;              /* Transparent: PerfectTransmitter.kt  material.py:133 */
+    /* relative index of refraction for a ray that arrives on the side the normal points
+     * to (n.wo >= 0) and for one that arrives from the other side:
+     *   Transparent  ior, 1/ior              material.py:147-152
+     *   Dielectric   eta_in/eta_out, eta_out/eta_in   material.py:174-177 */
+    double eta_front;
+    double eta_back;
+    double filter_in[3];    /* Dielectric cf_in / cf_out  material.py:445-446      */
+    double filter_out[3];
 } rtamd_material;
 
 typedef struct rtamd_light {

@@ -53,6 +53,9 @@ PLAN = {
     "features_analytic": ("parallel", None, 6000),
     "features_mesh":    ("parallel", None, 3000),
     "features_env":     ("parallel", None, 4000),
+    "features_glass":   ("parallel", None, 5000),
+    "features_pane":    ("parallel", None, 3000),
+    "glass_teapot":     ("parallel", None, 2500),
 }
 
 

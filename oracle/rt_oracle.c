@@ -17,6 +17,9 @@
  * Input is the scene layout of include/raytracer_amd.h with HOST pointers.
  * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp).
  */
+#ifdef RTO_DEBUG_RAYS
+#include <stdio.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -449,6 +452,9 @@ static int hit_objects(ctx_t *c, const ray_t *r, hit_t *best) {
     double tmin = T_INF;
     int found = 0, i;
     c->w.closest++;
+#ifdef RTO_DEBUG_RAYS
+    fprintf(stderr, "closest %.17g %.17g %.17g %.17g %.17g %.17g\n", r->o.x, r->o.y, r->o.z, r->d.x, r->d.y, r->d.z);
+#endif
     for (i = 0; i < c->S->n_objects; ++i) {
         hit_t h;
         if (object_hit(c, i, r, &h) && h.t < tmin) {
@@ -557,7 +563,22 @@ static vec direct(ctx_t *c, const rtamd_material *m, const hit_t *h, vec wo, int
     return L;
 }
 
-static vec trace_ray(ctx_t *c, ray_t ray, int depth);
+static vec trace_ray_t(ctx_t *c, ray_t ray, int depth, double *tmin_out);
+static vec trace_ray(ctx_t *c, ray_t ray, int depth) { return trace_ray_t(c, ray, depth, NULL); }
+
+/* refraction set-up shared by PerfectTransmitter (material.py:135-159) and the Fresnel pair
+ * (:170-223): flips the normal and picks the relative index by the side the ray arrives on */
+static int refraction(const rtamd_material *m, vec n, vec d, vec *nf, double *eta, double *cos_i, double *temp) {
+    double c = -dot(n, d);
+    *nf = n;
+    *eta = m->eta_front;
+    if (c < 0.) { c = -c; *nf = neg(n); *eta = m->eta_back; }
+    *cos_i = c;
+    *temp = 1. - (1. - c * c) / (*eta * *eta);
+    return *temp < 0.;                       /* total internal reflection */
+}
+
+static vec powv(vec b, double e) { return V(pow(b.x, e), pow(b.y, e), pow(b.z, e)); }
 
 /* material.shade / area_light_shade / path_shade for the hit's material */
 static vec shade(ctx_t *c, const hit_t *h, const ray_t *ray, int depth) {
@@ -566,7 +587,8 @@ static vec shade(ctx_t *c, const hit_t *h, const ray_t *ray, int depth) {
     vec wo = neg(ray->d), L;
     ray_t child;
     if (m->kind == RTAMD_EMISSIVE) {
-        if (S->tracer_kind == RTAMD_TRACER_SHADE) return V(1., 1., 1.);                   /* material.py:495-496 */
+        if (S->tracer_kind == RTAMD_TRACER_SHADE || S->tracer_kind == RTAMD_TRACER_WHITTED)
+            return V(1., 1., 1.);                                                          /* material.py:495-496 */
         if (S->tracer_kind == RTAMD_TRACER_AREA)
             return (-dot(h->n, ray->d) > 0) ? P3(m->emit) : V(0, 0, 0);                    /* material.py:498-502 */
         return (dot(h->n, ray->d) < 0) ? P3(m->emit) : V(0, 0, 0);                         /* material.py:504-508 */
@@ -608,17 +630,66 @@ static vec shade(ctx_t *c, const hit_t *h, const ray_t *ray, int depth) {
         else fr = scl(P3(m->reflect), lobe);
         child.o = h->p; child.d = wi;
         L = add(L, dvd(scl(mul(fr, trace_ray(c, child, depth + 1)), dot(h->n, wi)), pdf));
+    } else if (m->kind == RTAMD_TRANSPARENT) {                                             /* material.py:420-437 */
+        double ndotwo = dot(h->n, wo), pdf, eta, cos_i, temp;
+        vec wi = add(neg(wo), scl(scl(h->n, 2.0), ndotwo)), fr, nf, Lr;
+        int tir;
+        pdf = dot(h->n, wi);
+        fr = dvd(P3(m->reflect), pdf);
+        child.o = h->p; child.d = wi;
+        Lr = trace_ray(c, child, depth + 1);
+        tir = refraction(m, h->n, ray->d, &nf, &eta, &cos_i, &temp);
+        if (tir) {
+            L = add(L, Lr);
+        } else {
+            double cos_t = pow(temp, 0.5), ft;
+            vec wt = sub(dvd(neg(wo), eta), scl(nf, cos_t - cos_i / eta));
+            ft = m->kt / (eta * eta) / fabs(dot(h->n, wt));
+            L = add(L, mul(scl(Lr, dot(h->n, wi)), fr));
+            child.d = wt;
+            L = add(L, scl(scl(trace_ray(c, child, depth + 1), ft), fabs(dot(h->n, wt))));
+        }
+    } else if (m->kind == RTAMD_DIELECTRIC) {                                              /* material.py:448-483 */
+        double eta, cos_i, temp, cos_t, r_par, r_perp, kr, ndotwo = dot(h->n, wo), ndotwi, tr = 0, tt = 0, fr;
+        vec nf, wi, Lr;
+        int tir = refraction(m, h->n, ray->d, &nf, &eta, &cos_i, &temp);
+        cos_t = pow(temp, 0.5);                                                            /* NaN under TIR, unused then */
+        r_par = (eta * cos_i - cos_t) / (eta * cos_i + cos_t);
+        r_perp = (cos_i - eta * cos_t) / (cos_i + eta * cos_t);
+        kr = .5 * (r_par * r_par + r_perp * r_perp);
+        wi = add(neg(wo), scl(scl(h->n, 2.0), ndotwo));
+        ndotwi = dot(h->n, wi);
+        fr = kr / fabs(ndotwi);
+        child.o = h->p; child.d = wi;
+        if (tir) {
+            Lr = trace_ray_t(c, child, depth + 1, &tr);
+            L = add(L, mul(Lr, powv(ndotwi < 0. ? P3(m->filter_in) : P3(m->filter_out), tr)));
+        } else {
+            vec wt = sub(dvd(neg(wo), eta), scl(nf, cos_t - cos_i / eta)), Lt;
+            double ft = (1 - kr) / (eta * eta) / fabs(dot(h->n, wt)), ndotwt = dot(h->n, wt);
+            vec cr = ndotwi < 0. ? P3(m->filter_in) : P3(m->filter_out);
+            vec ct = ndotwi < 0. ? P3(m->filter_out) : P3(m->filter_in);
+            Lr = trace_ray_t(c, child, depth + 1, &tr);
+            child.d = wt;
+            Lt = trace_ray_t(c, child, depth + 1, &tt);
+            L = add(L, scl(mul(scl(Lr, fr), powv(cr, tr)), fabs(ndotwi)));
+            L = add(L, scl(mul(scl(Lt, ft), powv(ct, tt)), fabs(ndotwt)));
+        }
     }
     return L;
 }
 
-/* Tracer / AreaLightTracer / PathTracer .trace_ray: tracer.py:26-35, :65-71, :79-88 */
-static vec trace_ray(ctx_t *c, ray_t ray, int depth) {
+/* Tracer / WhittedTracer / AreaLightTracer / PathTracer .trace_ray: tracer.py:26-35, :43-58,
+ * :65-71, :79-88.  tmin_out is WhittedTracer's tminlist: the hit distance, 0 without a hit. */
+static vec trace_ray_t(ctx_t *c, ray_t ray, int depth, double *tmin_out) {
     const rtamd_scene_desc *S = c->S;
-    vec miss = S->tracer_kind == RTAMD_TRACER_SHADE ? P3(S->background) : V(0, 0, 0);
+    int shade_kind = S->tracer_kind == RTAMD_TRACER_SHADE || S->tracer_kind == RTAMD_TRACER_WHITTED;
+    vec miss = shade_kind ? P3(S->background) : V(0, 0, 0);
     hit_t h;
+    if (tmin_out) *tmin_out = 0;
     if (S->tracer_kind != RTAMD_TRACER_AREA && depth > S->depth_limit) return miss;
     if (!hit_objects(c, &ray, &h)) return miss;
+    if (tmin_out) *tmin_out = h.t;
     if (!c->have_first) {
         c->have_first = 1; c->first_object = h.object; c->first_prim = h.prim; c->first_t = h.t;
     }

@@ -2,7 +2,8 @@
 
 Constructor signatures, attribute names and setters follow
 /root/reference/material.py (`Matte` :232, `Phong` :329, `Reflective` :380,
-`GlossyReflective` :397, `Emissive` :486 and the BRDF holders :31-121).  The shading
+`GlossyReflective` :397, `Transparent` :414, `Dielectric` :440, `Emissive` :486 and the
+BRDF / BTDF holders :31-229).  The shading
 arithmetic itself lives in the kernels (csrc/rt_device.h); `device_record()` gives the
 per-material constants the way the reference would evaluate them once per call:
 `ka*cd` (Lambertian.rho :55-56), `kd*cd/pi` (Lambertian.f :38-39), `ks*cs`
@@ -10,7 +11,7 @@ per-material constants the way the reference would evaluate them once per call:
 """
 import numpy
 
-MATTE, PHONG, REFLECTIVE, GLOSSY_REFLECTIVE, EMISSIVE = range(5)
+MATTE, PHONG, REFLECTIVE, GLOSSY_REFLECTIVE, EMISSIVE, TRANSPARENT, DIELECTRIC = range(7)
 
 
 def _rgb(value):
@@ -50,6 +51,41 @@ class GlossySpecular(BDRF):
         self.ks = ks
         self.cs = cs
         self.exp = exp
+
+
+class BTDF(object):
+    def __init__(self, sampler=None):
+        self.sampler = sampler
+
+
+class PerfectTransmitter(BTDF):
+    def __init__(self, ior, kt, sampler=None):
+        super(PerfectTransmitter, self).__init__(sampler)
+        self.ior = ior
+        self.kt = kt
+
+
+class FresnelTransmitter(BTDF):
+    def __init__(self, sampler, kd, cd, eta_in, eta_out):
+        super(FresnelTransmitter, self).__init__(sampler)
+        self.eta_in = eta_in
+        self.eta_out = eta_out
+        self.kd = kd
+        self.cd = cd
+
+
+class FresnelReflector(PerfectSpecular):
+    def __init__(self, sampler, kd, cd, eta_in, eta_out):
+        super(FresnelReflector, self).__init__(sampler, kd, cd)
+        self.eta_in = eta_in
+        self.eta_out = eta_out
+
+
+def _py2_div(a, b):
+    """`a / b` as Python 2 evaluates it: floor division when both are plain integers."""
+    if isinstance(a, int) and isinstance(b, int) and not isinstance(a, bool) and not isinstance(b, bool):
+        return a // b
+    return a / b
 
 
 class Matte(Material):
@@ -146,8 +182,50 @@ class Emissive(Material):
                     receives_shadow=self.receives_shadow)
 
 
+class Transparent(Phong):
+    """Phong plus a mirror child and a refracted child (material.py:414-437)."""
+    KIND = TRANSPARENT
+
+    def __init__(self, ka, kd, ks, cd, exp, sampler, ior, kt, kr):
+        super(Transparent, self).__init__(ka, kd, ks, cd, exp, sampler)
+        self.reflective_bdrf = PerfectSpecular(sampler, kr, cd)
+        self.specular_btrf = PerfectTransmitter(ior, kt)
+
+    def device_record(self):
+        rec = super(Transparent, self).device_record()
+        rec["reflect"] = _rgb(self.reflective_bdrf.kd * self.reflective_bdrf.cd)
+        ior = self.specular_btrf.ior
+        rec["eta_front"] = float(ior)
+        rec["eta_back"] = float(1.0 / ior)          # material.py:140, :152
+        rec["kt"] = float(self.specular_btrf.kt)
+        return rec
+
+
+class Dielectric(Phong):
+    """Phong plus Fresnel-weighted reflected and refracted children whose radiance is
+    filtered by cf^t over the child's path length (material.py:440-483)."""
+    KIND = DIELECTRIC
+
+    def __init__(self, ka, kd, ks, cd, exp, sampler, eta_in, eta_out, cf_in, cf_out):
+        super(Dielectric, self).__init__(ka, kd, ks, cd, exp, sampler)
+        self.fresnel_brdf = FresnelReflector(sampler, kd, cd, eta_in, eta_out)
+        self.fresnel_btdf = FresnelTransmitter(sampler, kd, cd, eta_in, eta_out)
+        self.cf_in = cf_in
+        self.cf_out = cf_out
+
+    def device_record(self):
+        rec = super(Dielectric, self).device_record()
+        fb = self.fresnel_brdf
+        # the reflector and the transmitter are built from the same pair (:443-444)
+        rec["eta_front"] = float(_py2_div(fb.eta_in, fb.eta_out))       # material.py:177, :190, :214
+        rec["eta_back"] = float(_py2_div(fb.eta_out, fb.eta_in))        # material.py:175, :187, :212
+        rec["filter_in"] = _rgb(self.cf_in)
+        rec["filter_out"] = _rgb(self.cf_out)
+        return rec
+
+
 class _HostOnly(Material):
-    """Materials the device path does not cover (texture lookups, two-child recursion)."""
+    """Materials the device path does not cover (texture lookups)."""
 
     def __init__(self, *args, **kwargs):
         super(_HostOnly, self).__init__()
@@ -158,12 +236,4 @@ class _HostOnly(Material):
 
 
 class SV_Matte(_HostOnly):
-    pass
-
-
-class Transparent(_HostOnly):
-    pass
-
-
-class Dielectric(_HostOnly):
     pass

@@ -1,7 +1,7 @@
 """Ray / shade-record value types, the tracer flavours and the view plane.
 
 Interface of /root/reference/tracer.py: `Ray` :7, `ShadeRecord` :13, `Tracer` :21,
-`AreaLightTracer` :61, `PathTracer` :74, `ViewPlane` :91.  A tracer here is a
+`WhittedTracer` :38, `AreaLightTracer` :61, `PathTracer` :74, `ViewPlane` :91.  A tracer here is a
 description (kind + depth limit) that the flattener turns into kernel parameters;
 `trace_ray` hands the ray to the device through the owning world.
 """
@@ -68,7 +68,8 @@ class PathTracer(_DeviceTracer):
 
 
 class WhittedTracer(_DeviceTracer):
-    """Two-child recursion for dielectrics (tracer.py:38-58): not on the device path."""
+    """As `Tracer`, and also tells the calling material how far the ray went
+    (tracer.py:38-58); `Dielectric.shade` filters its children's radiance by that length."""
     KIND = "whitted"
 
 

@@ -7,12 +7,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(HERE, "csrc", "librtamd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+MAX_BRANCH_LEVELS = 8
 N_COUNTERS = 8
 COUNT_WORK = 1
 
 SPHERE, PLANE, CHECKER_PLANE, RECTANGLE, BOX, TRIANGLE, KDTREE = range(7)
-TRACER_SHADE, TRACER_AREA, TRACER_PATH = range(3)
+TRACER_SHADE, TRACER_AREA, TRACER_PATH, TRACER_WHITTED = range(4)
 
 d3 = C.c_double * 3
 
@@ -29,7 +30,8 @@ class Material(C.Structure):
     _fields_ = [("kind", C.c_int32), ("receives_shadow", C.c_int32), ("sampler", C.c_int32),
                 ("reserved", C.c_int32),
                 ("ambient", d3), ("diffuse", d3), ("specular", d3), ("exp", C.c_double),
-                ("reflect", d3), ("reflect_exp", C.c_double), ("emit", d3), ("pad_", C.c_double)]
+                ("reflect", d3), ("reflect_exp", C.c_double), ("emit", d3), ("kt", C.c_double),
+                ("eta_front", C.c_double), ("eta_back", C.c_double), ("filter_in", d3), ("filter_out", d3)]
 
 
 class Light(C.Structure):

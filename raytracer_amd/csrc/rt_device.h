@@ -855,34 +855,81 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
 
 struct Primary { int32_t object, prim; double t; };
 
-// tracer.trace_ray (tracer.py:26-35, :65-71, :79-88) for the 64 samples of a wave.  The
-// single-child recursion of Reflective / GlossyReflective / Matte.path_shade
+// A child ray of a Transparent / Dielectric hit that waits while its sibling's subtree is
+// traced: ray, product of the weights down to it, and Dielectric's colour filter, which is
+// raised to the child's own hit distance once that is known (material.py:463-482).
+struct PendingRay {
+    V3 o, d, W, filter;
+    int32_t depth, has_filter;
+};
+
+// Side of the surface a ray arrives on, relative index and the discriminant of Snell's law:
+// PerfectTransmitter (material.py:135-159) and FresnelReflector/Transmitter (:170-223).
+__device__ __forceinline__ bool refraction(const rtamd_material& m, V3 n, V3 d, V3& nf, double& eta,
+                                           double& cos_i, double& temp) {
+    double c = -dot(n, d);
+    nf = n;
+    eta = m.eta_front;
+    if (c < 0.) { c = -c; nf = -n; eta = m.eta_back; }
+    cos_i = c;
+    temp = 1. - (1. - c * c) / (eta * eta);
+    return temp < 0.;
+}
+
+__device__ __forceinline__ V3 powv(V3 b, double e) { return v3(pow(b.x, e), pow(b.y, e), pow(b.z, e)); }
+
+// tracer.trace_ray (tracer.py:26-35, :43-58, :65-71, :79-88) for the 64 samples of a wave.
+// The single-child recursion of Reflective / GlossyReflective / Matte.path_shade
 // (material.py:385-411, :283-289) is unrolled into a loop: radiance = sum over bounces of
 // (product of the child weights so far) * local term.  Lanes whose path has ended stay in
 // the loop as helpers for the wave-wide kd leaf tests until every lane is done.
-template <bool COUNT>
+//
+// BRANCH: the scene holds Transparent / Dielectric materials, whose two children per hit
+// (material.py:428-436, :473-474) make the recursion a tree.  Each lane walks its tree
+// depth first in the reference's order - reflected subtree, then the refracted one - with
+// the waiting siblings in a per-lane list (one per level, RTAMD_MAX_BRANCH_LEVELS), so the
+// in-trace draw counter advances exactly as in the recursive formulation.
+template <bool COUNT, bool BRANCH>
 __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, Primary& first) {
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
-    const V3 background = (S.tracer_kind == RTAMD_TRACER_SHADE) ? ld3(S.background) : v3(0, 0, 0);
+    const bool shade_kind = S.tracer_kind == RTAMD_TRACER_SHADE || S.tracer_kind == RTAMD_TRACER_WHITTED;
+    const V3 background = shade_kind ? ld3(S.background) : v3(0, 0, 0);
     const bool area = S.tracer_kind == RTAMD_TRACER_AREA;
     first.object = -1; first.prim = -1; first.t = 0;
     bool primary = true;
-    for (;; ++depth) {
-        if (alive && !area && depth > S.depth_limit) { L = L + W * background; alive = false; }
-        if (!__ballot(alive)) break;
+    PendingRay pending[BRANCH ? RTAMD_MAX_BRANCH_LEVELS : 1];
+    int n_pending = 0;
+    int lane_depth = depth;                 // BRANCH: lanes sit at different levels of their trees
+    V3 filter = v3(1, 1, 1);
+    bool has_filter = false;
+    for (;; ++depth, ++lane_depth) {
+        if (BRANCH) {
+            if (!alive && n_pending > 0) {
+                const PendingRay& q = pending[--n_pending];
+                ray.o = q.o; ray.d = q.d; W = q.W; filter = q.filter;
+                lane_depth = q.depth; has_filter = q.has_filter != 0;
+                alive = true;
+            }
+            if (alive && !area && lane_depth > S.depth_limit) { L = L + W * background; alive = false; }
+            if (!__ballot(alive || n_pending > 0)) break;
+        } else {
+            if (alive && !area && depth > S.depth_limit) { L = L + W * background; alive = false; }
+            if (!__ballot(alive)) break;
+        }
         Hit h;
         h.p = v3(0, 0, 0); h.n = v3(0, 0, 1); h.material = 0;
         const bool hit = closest_hit_wave<COUNT>(S, stk, alive, ray, w, h);
         if (alive && !hit) { L = L + W * background; alive = false; }
         if (alive && primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; }
         primary = false;
+        if (BRANCH && alive && has_filter) { W = W * powv(filter, h.t); has_filter = false; }
         const rtamd_material& m = S.materials[alive ? h.material : 0];
         const V3 wo = -ray.d;
 
         if (alive && m.kind == RTAMD_EMISSIVE) {
             V3 e;
-            if (S.tracer_kind == RTAMD_TRACER_SHADE) e = v3(1., 1., 1.);                           // material.py:495-496
+            if (shade_kind) e = v3(1., 1., 1.);                                                    // material.py:495-496
             else if (area) e = (-dot(h.n, ray.d) > 0) ? ld3(m.emit) : v3(0, 0, 0);                  // material.py:498-502
             else e = (dot(h.n, ray.d) < 0) ? ld3(m.emit) : v3(0, 0, 0);                             // material.py:504-508
             L = L + W * e;
@@ -937,6 +984,54 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
             if (pdf == 0) { fr = v3(0, 0, 0); pdf = 1; }
             else fr = ld3(m.reflect) * lobe;
             W = W * ((fr * dot(h.n, wi)) / pdf);
+            ray.o = h.p;
+            ray.d = wi;
+        } else if (BRANCH && m.kind == RTAMD_TRANSPARENT) {
+            // PerfectSpecular.sample_f (material.py:69-74), PerfectTransmitter (:135-159),
+            // Transparent.shade (:420-437)
+            const double ndotwo = dot(h.n, wo);
+            const V3 wi = (-wo) + (2.0 * h.n) * ndotwo;
+            const double pdf = dot(h.n, wi);
+            const V3 fr = ld3(m.reflect) / pdf;
+            V3 nf;
+            double eta, cos_i, temp;
+            if (!refraction(m, h.n, ray.d, nf, eta, cos_i, temp)) {
+                const double cos_t = sqrt(temp);
+                const V3 wt = ((-wo) / eta) - (cos_t - cos_i / eta) * nf;
+                const double ft = m.kt / (eta * eta) / fabs(dot(h.n, wt));
+                PendingRay& q = pending[n_pending++];
+                q.o = h.p; q.d = wt; q.W = W * (ft * fabs(dot(h.n, wt)));
+                q.filter = v3(1, 1, 1); q.has_filter = 0; q.depth = lane_depth + 1;
+                W = W * (dot(h.n, wi) * fr);
+            }
+            ray.o = h.p;
+            ray.d = wi;
+        } else if (BRANCH && m.kind == RTAMD_DIELECTRIC) {
+            // FresnelReflector.fresnel / sample_f (material.py:206-229), FresnelTransmitter
+            // (:170-197), Dielectric.shade (:448-483)
+            V3 nf;
+            double eta, cos_i, temp;
+            const bool tir = refraction(m, h.n, ray.d, nf, eta, cos_i, temp);
+            const double ndotwo = dot(h.n, wo);
+            const V3 wi = (-wo) + (2.0 * h.n) * ndotwo;
+            const double ndotwi = dot(h.n, wi);
+            const bool inside = ndotwi < 0.;            // the reflected ray stays inside
+            if (!tir) {
+                const double cos_t = sqrt(temp);
+                const double r_par = (eta * cos_i - cos_t) / (eta * cos_i + cos_t);
+                const double r_perp = (cos_i - eta * cos_t) / (cos_i + eta * cos_t);
+                const double kr = .5 * (r_par * r_par + r_perp * r_perp);
+                const V3 wt = ((-wo) / eta) - (cos_t - cos_i / eta) * nf;
+                const double ndotwt = dot(h.n, wt);
+                const double ft = (1 - kr) / (eta * eta) / fabs(ndotwt);
+                PendingRay& q = pending[n_pending++];
+                q.o = h.p; q.d = wt; q.W = W * (ft * fabs(ndotwt));
+                q.filter = inside ? ld3(m.filter_out) : ld3(m.filter_in);
+                q.has_filter = 1; q.depth = lane_depth + 1;
+                W = W * ((kr / fabs(ndotwi)) * fabs(ndotwi));
+            }
+            filter = inside ? ld3(m.filter_in) : ld3(m.filter_out);
+            has_filter = true;
             ray.o = h.p;
             ray.d = wi;
         } else {

@@ -70,7 +70,10 @@ __device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point,
     return r;
 }
 
-template <int MODE, bool COUNT>
+// BRANCH instantiations serve scenes with two-child materials (Transparent, Dielectric);
+// they keep a per-lane list of waiting child rays in private memory, which the other
+// instantiations do not pay for.
+template <int MODE, bool COUNT, bool BRANCH>
 __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
     // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         KdStack stk;
         stk.node = stack_node;
         stk.t = stack_t;
-        const V3 c = trace_wave<COUNT>(S, stk, live, ray, A.depth0, dr, work, first);
+        const V3 c = trace_wave<COUNT, BRANCH>(S, stk, live, ray, A.depth0, dr, work, first);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
             if (A.out.rgb) { A.out.rgb[3 * k] = c.x; A.out.rgb[3 * k + 1] = c.y; A.out.rgb[3 * k + 2] = c.z; }
@@ -207,7 +210,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 template <int MODE>
-int launch(const rtamd_scene_desc& S, LaunchArgs& A, uint32_t flags, void* stream) {
+int launch(const rtamd_scene_desc& S, bool branching, LaunchArgs& A, uint32_t flags, void* stream) {
     if (A.n <= 0) return RTAMD_OK;
     A.seg_len = 0;
 #if RT_XCD_SEGMENTS > 0
@@ -220,10 +223,15 @@ int launch(const rtamd_scene_desc& S, LaunchArgs& A, uint32_t flags, void* strea
     if (A.seg_len > 0) blocks = A.seg_len * (RT_XCD_SEGMENTS > 0 ? RT_XCD_SEGMENTS : 1);   // padded: the remap is a bijection
     if (blocks > 0x7fffffffLL) return fail(RTAMD_EINVAL, "too many samples for one launch%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (flags & RTAMD_COUNT_WORK)
-        hipLaunchKernelGGL((trace_kernel<MODE, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, S, A);
-    else
-        hipLaunchKernelGGL((trace_kernel<MODE, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, S, A);
+    const bool count = (flags & RTAMD_COUNT_WORK) != 0;
+    const dim3 grid((unsigned)blocks), block(BLOCK);
+    if (branching) {
+        if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, true>), grid, block, 0, st, S, A);
+        else hipLaunchKernelGGL((trace_kernel<MODE, false, true>), grid, block, 0, st, S, A);
+    } else {
+        if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false>), grid, block, 0, st, S, A);
+        else hipLaunchKernelGGL((trace_kernel<MODE, false, false>), grid, block, 0, st, S, A);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return RTAMD_OK;
@@ -236,6 +244,7 @@ struct rtamd_scene {
     int device;
     rtamd_sampler* samplers_host;   // host copies of the small tables, for argument checks
     int max_tree_depth;
+    bool branching;                 // a Transparent / Dielectric material is traced recursively
 };
 
 extern "C" {
@@ -256,7 +265,7 @@ int rtamd_scene_destroy(rtamd_scene* scene);
 int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
     if (!d || !out) return fail(RTAMD_EINVAL, "null argument%s");
     if (d->abi_version != RTAMD_ABI_VERSION) return fail(RTAMD_EINVAL, "descriptor ABI version mismatch%s");
-    if (d->tracer_kind < RTAMD_TRACER_SHADE || d->tracer_kind > RTAMD_TRACER_PATH)
+    if (d->tracer_kind < RTAMD_TRACER_SHADE || d->tracer_kind > RTAMD_TRACER_WHITTED)
         return fail(RTAMD_EUNSUPPORTED, "unknown tracer kind%s");
     if (d->n_objects < 0 || d->n_materials < 0 || d->n_lights < 0 || d->n_samplers < 1 || d->n_trees < 0)
         return fail(RTAMD_EINVAL, "negative table size, or no view-plane sampler%s");
@@ -280,6 +289,7 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
     s->desc = *d;
     s->device = dev;
     s->max_tree_depth = 0;
+    s->branching = false;
     s->samplers_host = new (std::nothrow) rtamd_sampler[d->n_samplers];
     if (!s->samplers_host) { delete s; return fail(RTAMD_EINVAL, "out of host memory%s"); }
     e = hipMemcpy(s->samplers_host, d->samplers, sizeof(rtamd_sampler) * d->n_samplers, hipMemcpyDeviceToHost);
@@ -300,7 +310,21 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
         e = hipMemcpy(&m, d->materials + i, sizeof(m), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the material table"); }
         const bool draws = m.kind == RTAMD_GLOSSY_REFLECTIVE || (d->tracer_kind == RTAMD_TRACER_PATH && m.kind == RTAMD_MATTE);
-        if (m.kind < RTAMD_MATTE || m.kind > RTAMD_EMISSIVE) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "unknown material kind%s"); }
+        if (m.kind < RTAMD_MATTE || m.kind > RTAMD_DIELECTRIC) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "unknown material kind%s"); }
+        const bool two_children = m.kind == RTAMD_TRANSPARENT || m.kind == RTAMD_DIELECTRIC;
+        if (two_children && d->tracer_kind != RTAMD_TRACER_AREA) {
+            // Dielectric.shade hands trace_ray a third argument (material.py:459); only
+            // WhittedTracer accepts it (tracer.py:43)
+            if (m.kind == RTAMD_DIELECTRIC && d->tracer_kind != RTAMD_TRACER_WHITTED) {
+                rtamd_scene_destroy(s);
+                return fail(RTAMD_EUNSUPPORTED, "a Dielectric material needs the Whitted tracer%s");
+            }
+            if (d->depth_limit + 1 > RTAMD_MAX_BRANCH_LEVELS) {
+                rtamd_scene_destroy(s);
+                return fail(RTAMD_EUNSUPPORTED, "depth limit too large for two-child materials%s");
+            }
+            s->branching = true;
+        }
         if (d->tracer_kind == RTAMD_TRACER_PATH && m.kind != RTAMD_MATTE && m.kind != RTAMD_EMISSIVE) {
             rtamd_scene_destroy(s);
             return fail(RTAMD_EUNSUPPORTED, "the path tracer needs Matte or Emissive materials%s");
@@ -379,7 +403,7 @@ int rtamd_render_pixels(rtamd_scene* scene, const rtamd_camera* camera, uint64_t
     A.b3 = lens_points;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_PIXELS>(scene->desc, A, flags, stream);
+    return launch<MODE_PIXELS>(scene->desc, scene->branching, A, flags, stream);
 }
 
 int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t* pixel_index,
@@ -390,6 +414,7 @@ int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t
     if (n < 0) return fail(RTAMD_EINVAL, "negative ray count%s");
     if (n == 0) return RTAMD_OK;
     if (!origins || !directions || !out) return fail(RTAMD_EINVAL, "null ray buffer%s");
+    if (scene->branching && depth < 0) return fail(RTAMD_EINVAL, "negative start depth in a scene with two-child materials%s");
     LaunchArgs A;
     memset(&A, 0, sizeof(A));
     A.trace_key = phase_key(seed, PHASE_TRACE);
@@ -402,7 +427,7 @@ int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t
     A.depth0 = depth;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_RAYS>(scene->desc, A, flags, stream);
+    return launch<MODE_RAYS>(scene->desc, scene->branching, A, flags, stream);
 }
 
 int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t seed, int64_t n_tiles,
@@ -430,7 +455,7 @@ int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t 
     A.sum_rgb8 = sum_rgb8;
     A.sum_sq = sum_sq;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_TILES>(scene->desc, A, flags, stream);
+    return launch<MODE_TILES>(scene->desc, scene->branching, A, flags, stream);
 }
 
 }  // extern "C"

@@ -111,11 +111,11 @@ class _Flattener(object):
             m.kind = rec["kind"]
             m.receives_shadow = int(bool(rec.get("receives_shadow", True)))
             m.sampler = self.sampler_id(rec.get("sampler"))
-            for field in ("ambient", "diffuse", "specular", "reflect", "emit"):
+            for field in ("ambient", "diffuse", "specular", "reflect", "emit", "filter_in", "filter_out"):
                 if field in rec:
                     _fill(getattr(m, field), rec[field])
-            m.exp = rec.get("exp", 0.0)
-            m.reflect_exp = rec.get("reflect_exp", 0.0)
+            for field in ("exp", "reflect_exp", "kt", "eta_front", "eta_back"):
+                setattr(m, field, rec.get(field, 0.0))
             self.material_ids[key] = len(self.materials)
             self.materials.append(m)
         return self.material_ids[key]
@@ -299,6 +299,8 @@ def flatten_world(world):
         scene.tracer_kind = capi.TRACER_AREA
     elif kind == "path":
         scene.tracer_kind = capi.TRACER_PATH
+    elif kind == "whitted":
+        scene.tracer_kind = capi.TRACER_WHITTED
     else:
         raise NotImplementedError("tracer %r is outside the device hot path" % type(tracer).__name__)
     scene.depth_limit = int(getattr(tracer, "depth_limit", 0))
@@ -320,6 +322,14 @@ def flatten_world(world):
     for m in fl.materials:
         if scene.tracer_kind == capi.TRACER_PATH and m.kind not in (M.MATTE, M.EMISSIVE):
             raise NotImplementedError("PathTracer needs path_shade, which only Matte and Emissive have")
+        if m.kind == M.DIELECTRIC and scene.tracer_kind in (capi.TRACER_SHADE, capi.TRACER_PATH):
+            # Dielectric.shade passes a third argument that only WhittedTracer.trace_ray takes
+            # (material.py:459 vs tracer.py:26, :43)
+            raise TypeError("Dielectric needs a WhittedTracer")
+        if (m.kind in (M.TRANSPARENT, M.DIELECTRIC) and scene.tracer_kind != capi.TRACER_AREA
+                and scene.depth_limit + 1 > capi.MAX_BRANCH_LEVELS):
+            raise NotImplementedError("two-child materials are traced to depth_limit <= %d on the device"
+                                      % (capi.MAX_BRANCH_LEVELS - 1))
         samples_lobe = m.kind == M.GLOSSY_REFLECTIVE or (scene.tracer_kind == capi.TRACER_PATH and m.kind == M.MATTE)
         if samples_lobe and m.sampler < 0:
             # the reference fails here too: `None.sample_unit_hemisphere_surface` (material.py:47, :110)

@@ -9,7 +9,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 
 GOLDEN_SCENES = ("foursphere", "glossyreflective", "mirrorhall", "mirrorhall_dof", "cornellbox",
-                 "cornellbox_area", "features_analytic", "features_mesh", "features_env", "j", "dragon_area")
+                 "cornellbox_area", "features_analytic", "features_mesh", "features_env", "features_glass",
+                 "features_pane", "glass_teapot", "j", "dragon_area")
 
 # float comparison bound for radiance: the tolerance of the task statement is 1e-4
 # relative per channel (fp32 device vs Python float64); this build computes in double, so

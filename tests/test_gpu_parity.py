@@ -36,6 +36,9 @@ def test_gpu_matches_reference_golden(torch_gpu, scene):
     ("features_analytic", 80, (0, 9)),
     ("features_mesh", 60, (0, 4)),
     ("features_env", 60, (2, 7)),
+    ("features_glass", 60, (0, 9)),
+    ("features_pane", 40, (1, 4)),
+    ("glass_teapot", 80, (0, 4)),
     ("dragon_area", 40, (0, 4)),
     ("dragon_area", 420, (0, 16)),
     ("j", 600, (0, 1)),
@@ -227,3 +230,46 @@ def test_trace_rays_start_depth(torch_gpu):
     assert (last["n_rays"][:, 0] == 1).all()
     full = ds.trace_rays(world.seed, g["origin"], g["direction"], pix, smp, depth=0)
     assert numpy.array_equal(full["n_rays"], g["n_rays"])
+
+
+def test_two_child_materials_are_checked_by_the_library(torch_gpu):
+    """rtamd_scene_create refuses what the reference cannot run (Dielectric under a tracer
+    without the three-argument trace_ray) and ray trees deeper than its per-sample list of
+    waiting rays; rtamd_trace_rays refuses a negative start depth for such scenes."""
+    import ctypes as C
+    from raytracer_amd import capi, runtime
+    world = common.world_for("features_glass")
+    ds = runtime.device_scene(world)
+    lib = capi.library()
+
+    def create(**changes):
+        desc = ds.flat.desc(lambda name, arr: ds.tensors[name].data_ptr())
+        desc.tri_order = ds.tensors["tri_order"].data_ptr()
+        desc.chunk_boxes = ds.tensors["chunk_boxes"].data_ptr()
+        for k, v in changes.items():
+            setattr(desc, k, v)
+        handle = C.c_void_p()
+        rc = lib.rtamd_scene_create(C.byref(desc), C.byref(handle))
+        if rc == 0:
+            lib.rtamd_scene_destroy(handle)
+        return rc, lib.rtamd_last_error()
+    assert create()[0] == 0
+    rc, msg = create(tracer_kind=capi.TRACER_SHADE)
+    assert rc != 0 and b"Whitted" in msg
+    rc, msg = create(depth_limit=capi.MAX_BRANCH_LEVELS)
+    assert rc != 0 and b"depth limit" in msg
+    assert create(depth_limit=capi.MAX_BRANCH_LEVELS - 1)[0] == 0
+    assert create(tracer_kind=capi.TRACER_AREA, depth_limit=50)[0] == 0     # area_light_shade does not recurse
+    with pytest.raises(Exception, match="start depth"):
+        ds.trace_rays(world.seed, numpy.zeros((1, 3)), numpy.array([[0., 0., -1.]]), depth=-1)
+    # a start depth inside the tree works and matches the oracle
+    from oracle import oracle
+    g = common.golden("features_glass")
+    pix, smp, _, _ = common.golden_inputs("features_glass")
+    k = slice(0, 512)
+    got = ds.trace_rays(world.seed, g["origin"][k], g["direction"][k], pix[k], smp[k], depth=2)
+    want = oracle.OracleScene(common.flat_for("features_glass")).trace_rays(
+        world.seed, g["origin"][k], g["direction"][k], pix[k], smp[k], depth=2)
+    assert numpy.array_equal(got["n_rays"], want["n_rays"])
+    close, worst = common.rgb_close(got["rgb"], want["rgb"])
+    assert close, worst

@@ -138,13 +138,36 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
 def test_unsupported_scene_features_are_refused():
     import material, tracer
     with pytest.raises(NotImplementedError):
-        material.Dielectric().device_record()
+        material.SV_Matte().device_record()
     from raytracer_amd import flatten
     from raytracer_amd.world import World
-    world = World(viewmode="realtime", buildfunction="foursphere")
-    world.tracer = tracer.WhittedTracer(world)
+    # Dielectric.shade needs the three-argument trace_ray that only WhittedTracer has
+    world = World(viewmode="realtime", buildfunction="features_glass")
+    flatten.flatten_world(world)
+    world.tracer = tracer.Tracer(world, 4)
+    with pytest.raises(TypeError):
+        flatten.flatten_world(world)
+    # one waiting child ray per level of the ray tree: the device bounds the levels
+    world.tracer = tracer.WhittedTracer(world, 8)
     with pytest.raises(NotImplementedError):
         flatten.flatten_world(world)
+    world.tracer = tracer.WhittedTracer(world, 7)
+    flatten.flatten_world(world)
+
+
+def test_glass_material_records():
+    """Relative indices by arrival side, with Python 2's integer division where the
+    reference would have used it (material.py:175-177)."""
+    import material
+    d = material.Dielectric(0, 0, 0, numpy.ones(3), 0, None, eta_in=0.8, eta_out=1, cf_in=.9, cf_out=numpy.array((.9, .6, .5)))
+    rec = d.device_record()
+    assert rec["eta_front"] == 0.8 and rec["eta_back"] == 1 / 0.8
+    assert numpy.array_equal(rec["filter_in"], [.9, .9, .9]) and numpy.array_equal(rec["filter_out"], [.9, .6, .5])
+    ints = material.Dielectric(0, 0, 0, numpy.ones(3), 0, None, eta_in=3, eta_out=2, cf_in=1, cf_out=1).device_record()
+    assert ints["eta_front"] == 1.0 and ints["eta_back"] == 0.0
+    t = material.Transparent(0, 0, 0, numpy.ones(3), 0., None, ior=1.25, kt=.9, kr=.1).device_record()
+    assert t["eta_front"] == 1.25 and t["eta_back"] == 0.8 and t["kt"] == .9
+    assert numpy.allclose(t["reflect"], .1)
 
 
 REFERENCE_SCENES = "/root/reference/buildfunctions"
@@ -154,7 +177,7 @@ REFERENCE_SCENES = "/root/reference/buildfunctions"
 @pytest.mark.parametrize("name,twin", [("foursphere", "foursphere"), ("glossyreflective", "glossyreflective"),
                                        ("mirrorhall", "mirrorhall"), ("i", None), ("a", None), ("b", None),
                                        ("c", None), ("d", None), ("e", None), ("f", None), ("g", None),
-                                       ("glossyreflectivehall", None)])
+                                       ("glossyreflectivehall", None), ("transparent", None)])
 def test_reference_scene_files_load_unchanged(name, twin):
     """Drop-in check: the reference's own buildfunction files (those that are valid Python 3
     as they stand) build through this scene API and flatten; where this repo ships the same
