@@ -56,9 +56,14 @@ enum {
     RTAMD_MATTE = 0, RTAMD_PHONG = 1, RTAMD_REFLECTIVE = 2,
     RTAMD_GLOSSY_REFLECTIVE = 3, RTAMD_EMISSIVE = 4,
     RTAMD_TRANSPARENT = 5,   /* material.py:414-437: mirror child + refracted child    */
-    RTAMD_DIELECTRIC = 6     /* material.py:440-483: Fresnel-weighted children, colour
+    RTAMD_DIELECTRIC = 6,    /* material.py:440-483: Fresnel-weighted children, colour
                                 filter cf^t over the child's path length               */
+    RTAMD_SV_MATTE = 7       /* material.py:292-326: Matte whose colour is a texture lookup
+                                (`ambient` holds ka, `diffuse` holds kd, both broadcast) */
 };
+
+/* texture mappings (texture.py:53-68) */
+enum { RTAMD_MAP_SPHERICAL = 0 };
 
 /* light kinds (light.py) */
 enum { RTAMD_POINT = 0, RTAMD_DIRECTIONAL = 1, RTAMD_AREA = 2, RTAMD_ENVIRONMENT = 3 };
@@ -107,7 +112,7 @@ typedef struct rtamd_material {
     int32_t kind;
     int32_t receives_shadow;
     int32_t sampler;        /* glossy lobe / path tracing hemisphere sampler, or -1 */
-    int32_t reserved;
+    int32_t texture;        /* SV_MATTE: index into textures, else -1               */
     double ambient[3];      /* ka*cd            material.py:55-56                 */
     double diffuse[3];      /* kd*cd/pi         material.py:38-39                 */
     double specular[3];     /* ks*cs            material.py:95                    */
@@ -185,6 +190,18 @@ typedef struct rtamd_tree {
     int32_t reserved[3];
 } rtamd_tree;
 
+/* An ImageTexture (texture.py:11-46): 8-bit RGB texels, row-major from the top row as
+ * PIL's getpixel((column, row)) addresses them, at texels[offset + 3*(row*width + column)].
+ * hres/vres are the extents the mapping scales (u, v) by; they equal width/height unless the
+ * scene gave its own (texture.py:26-29) and never exceed them.  A colour is texel/256. */
+typedef struct rtamd_texture {
+    int32_t width, height;
+    int32_t hres, vres;
+    int32_t mapping;
+    int32_t reserved;
+    int64_t offset;         /* first byte of this image in texels                  */
+} rtamd_texture;
+
 /* Everything a render needs that does not change between frames.
  * Leaf-ordered triangle tables have one row per leaf reference (a triangle that
  * straddles a split plane appears once per leaf that holds it, kdtree.py:52):
@@ -235,6 +252,11 @@ typedef struct rtamd_scene_desc {
     const double *prim_normals;         /* device */
     const int64_t *prim_normal_offset;  /* device */
     const int32_t *prim_material;       /* device */
+    int32_t n_textures;
+    int32_t reserved;
+    int64_t n_texel_bytes;
+    const rtamd_texture *textures;      /* device, NULL when n_textures == 0 */
+    const uint8_t *texels;              /* device */
 } rtamd_scene_desc;
 
 /* Camera and view plane (camera.py:12-33, :142-146, :222-225; tracer.py:91-95). */

@@ -55,6 +55,7 @@ PLAN = {
     "features_env":     ("parallel", None, 4000),
     "features_glass":   ("parallel", None, 5000),
     "features_pane":    ("parallel", None, 3000),
+    "features_texture": ("parallel", None, 5000),
     "glass_teapot":     ("parallel", None, 2500),
 }
 

@@ -229,6 +229,7 @@ static int kd_next(kd_iter *it, work_t *w, int32_t *first, int32_t *count) {
 typedef struct {
     double t;
     vec n, p;
+    vec local;                  /* ShadeRecord.local_hit_point, in the object's own space */
     int material, object, prim;
 } hit_t;
 
@@ -406,6 +407,8 @@ static int object_hit(ctx_t *c, int idx, const ray_t *world_ray, hit_t *h) {
               (m[2] * n.x + m[5] * n.y) + m[8] * n.z);
     }
     h->t = t; h->n = n; h->material = mat; h->object = idx; h->prim = prim;
+    h->local = add(r->o, scl(r->d, t));                                   /* geometry.py:210, :323, :456 ... */
+    if (ob->kind == RTAMD_SPHERE) h->local = sub(h->local, P3(p));        /* geometry.py:271 */
     return 1;
 }
 
@@ -503,13 +506,35 @@ static vec glossy_f(vec spec, double e, vec n, vec wo, vec wi) {          /* mat
     return V(0, 0, 0);
 }
 
-/* Matte/Phong shade and area_light_shade: material.py:251-281, :346-377 */
+/* ImageTexture.get_color with SphericalMap.get_texel_coordinates, texture.py:33-68.  Python
+ * raises where acos leaves its domain or the texel lies outside the image; a NaN colour here. */
+static vec texture_color(const rtamd_scene_desc *S, int tex, vec local) {
+    const rtamd_texture *T = &S->textures[tex];
+    const double pi = 3.141592653589793;
+    double theta = acos(local.y), phi = atan2(local.x, local.z), u, v;
+    int column, row;
+    const uint8_t *px;
+    if (phi < 0.) phi += pi * 2;
+    u = phi / pi / 2;
+    v = 1 - theta / pi;
+    if (!(theta == theta)) return V(NAN, NAN, NAN);
+    column = (int)((T->hres - 1) * u);
+    row = (int)((T->vres - 1) * v);
+    if (column < 0 || column >= T->width || row < 0 || row >= T->height) return V(NAN, NAN, NAN);
+    px = S->texels + T->offset + 3 * ((int64_t)row * T->width + column);
+    return V(px[0] / 256., px[1] / 256., px[2] / 256.);
+}
+
+/* Matte/Phong shade and area_light_shade: material.py:251-281, :346-377; SV_Matte.shade :311-326 */
 static vec direct(ctx_t *c, const rtamd_material *m, const hit_t *h, vec wo, int area) {
     const rtamd_scene_desc *S = c->S;
-    vec L = mul(P3(m->ambient), ambient_L(c, h));
-    int phong = m->kind != RTAMD_MATTE;
+    int textured = m->kind == RTAMD_SV_MATTE;
+    vec ka = P3(m->ambient), kd = P3(m->diffuse), L;
+    int phong = m->kind != RTAMD_MATTE && !textured;
     int gate = (phong || area) ? m->receives_shadow : 1;
     int li;
+    if (textured) ka = mul(ka, texture_color(S, m->texture, h->local));   /* material.py:24-25 */
+    L = mul(ka, ambient_L(c, h));
     for (li = 0; li < S->n_lights; ++li) {
         const rtamd_light *lt = &S->lights[li];
         vec wi, sp = V(0, 0, 0), f, Ll, term;
@@ -532,6 +557,7 @@ static vec direct(ctx_t *c, const rtamd_material *m, const hit_t *h, vec wo, int
         }
         ndotwi = dot(h->n, wi);
         if (!(ndotwi > 0)) continue;
+        if (textured && !(dot(h->n, wo) > 0.)) continue;                  /* material.py:317-319 */
         if (lt->cast_shadow) {
             ray_t sr;
             sr.o = h->p; sr.d = wi;
@@ -540,7 +566,9 @@ static vec direct(ctx_t *c, const rtamd_material *m, const hit_t *h, vec wo, int
             else shadowed = in_shadow(c, &sr, 0, 0);
         }
         if (shadowed || !gate) continue;
-        f = P3(m->diffuse);
+        f = kd;
+        if (textured)                                                     /* material.py:27-28: one lookup per light */
+            f = dvd(mul(kd, texture_color(S, m->texture, h->local)), 3.141592653589793);
         if (phong) f = add(f, glossy_f(P3(m->specular), m->exp, h->n, wo, wi));
         Ll = P3(lt->radiance);
         if (lt->kind == RTAMD_POINT && lt->attenuation != 0)              /* light.py:39-44 */

@@ -1,7 +1,7 @@
 """Material descriptions: what the device shading code is parameterised by.
 
 Constructor signatures, attribute names and setters follow
-/root/reference/material.py (`Matte` :232, `Phong` :329, `Reflective` :380,
+/root/reference/material.py (`Matte` :232, `SV_Matte` :292, `Phong` :329, `Reflective` :380,
 `GlossyReflective` :397, `Transparent` :414, `Dielectric` :440, `Emissive` :486 and the
 BRDF / BTDF holders :31-229).  The shading
 arithmetic itself lives in the kernels (csrc/rt_device.h); `device_record()` gives the
@@ -11,7 +11,7 @@ per-material constants the way the reference would evaluate them once per call:
 """
 import numpy
 
-MATTE, PHONG, REFLECTIVE, GLOSSY_REFLECTIVE, EMISSIVE, TRANSPARENT, DIELECTRIC = range(7)
+MATTE, PHONG, REFLECTIVE, GLOSSY_REFLECTIVE, EMISSIVE, TRANSPARENT, DIELECTRIC, SV_MATTE = range(8)
 
 
 def _rgb(value):
@@ -43,6 +43,10 @@ class Lambertian(BDRF):
 
 class PerfectSpecular(Lambertian):
     pass
+
+
+class SV_Lambertian(Lambertian):
+    """Lambertian whose `cd` is a texture object (material.py:17-28)."""
 
 
 class GlossySpecular(BDRF):
@@ -224,16 +228,23 @@ class Dielectric(Phong):
         return rec
 
 
-class _HostOnly(Material):
-    """Materials the device path does not cover (texture lookups)."""
+class SV_Matte(Material):
+    """Matte with a texture for `cd` (material.py:292-326).  Its `shade` differs from
+    Matte's in one more way: a light only contributes when the viewer is on the normal's
+    side as well (`ndotwo > 0`, :319)."""
+    KIND = SV_MATTE
 
-    def __init__(self, *args, **kwargs):
-        super(_HostOnly, self).__init__()
-        self.args, self.kwargs = args, kwargs
+    def __init__(self, ka, kd, cd, sampler=None):
+        super(SV_Matte, self).__init__()
+        self.ambient_brdf = SV_Lambertian(None, ka, cd)
+        self.diffuse_brdf = SV_Lambertian(sampler, kd, cd)
+
+    set_ka = Matte.set_ka
+    set_kd = Matte.set_kd
+    set_cd = Matte.set_cd
 
     def device_record(self):
-        raise NotImplementedError("%s is outside the device hot path" % type(self).__name__)
-
-
-class SV_Matte(_HostOnly):
-    pass
+        if self.ambient_brdf.cd is not self.diffuse_brdf.cd:
+            raise NotImplementedError("SV_Matte with different ambient and diffuse textures")
+        return dict(kind=self.KIND, ambient=_rgb(self.ambient_brdf.kd), diffuse=_rgb(self.diffuse_brdf.kd),
+                    texture=self.diffuse_brdf.cd, receives_shadow=self.receives_shadow)

@@ -28,7 +28,7 @@ class Object(C.Structure):
 
 class Material(C.Structure):
     _fields_ = [("kind", C.c_int32), ("receives_shadow", C.c_int32), ("sampler", C.c_int32),
-                ("reserved", C.c_int32),
+                ("texture", C.c_int32),
                 ("ambient", d3), ("diffuse", d3), ("specular", d3), ("exp", C.c_double),
                 ("reflect", d3), ("reflect_exp", C.c_double), ("emit", d3), ("kt", C.c_double),
                 ("eta_front", C.c_double), ("eta_back", C.c_double), ("filter_in", d3), ("filter_out", d3)]
@@ -62,6 +62,11 @@ class Tree(C.Structure):
                 ("depth", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("hres", C.c_int32), ("vres", C.c_int32),
+                ("mapping", C.c_int32), ("reserved", C.c_int32), ("offset", C.c_int64)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("tracer_kind", C.c_int32), ("depth_limit", C.c_int32),
                 ("n_objects", C.c_int32), ("n_materials", C.c_int32), ("n_lights", C.c_int32),
@@ -74,7 +79,9 @@ class SceneDesc(C.Structure):
                 ("kd_nodes", C.c_void_p), ("tri_geom", C.c_void_p), ("tri_prim", C.c_void_p),
                 ("tri_order", C.c_void_p), ("chunk_boxes", C.c_void_p),
                 ("prim_normals", C.c_void_p), ("prim_normal_offset", C.c_void_p),
-                ("prim_material", C.c_void_p)]
+                ("prim_material", C.c_void_p),
+                ("n_textures", C.c_int32), ("reserved", C.c_int32), ("n_texel_bytes", C.c_int64),
+                ("textures", C.c_void_p), ("texels", C.c_void_p)]
 
 
 class Camera(C.Structure):

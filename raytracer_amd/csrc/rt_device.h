@@ -773,12 +773,43 @@ __device__ __forceinline__ V3 phong_lobe(V3 spec, double exp_, V3 n, V3 wo, V3 w
     return v3(0, 0, 0);
 }
 
+// ShadeRecord.local_hit_point of a hit: o + t*d in the object's own space (geometry.py:210,
+// :323, :456; through an Instance the child's record is kept, :103-108), relative to the
+// centre for a sphere (:271).
+__device__ __forceinline__ V3 local_hit_point(const rtamd_object& ob, const Ray& world_ray, double t) {
+    const Ray r = ob.has_transform ? to_object_space(ob, world_ray) : world_ray;
+    V3 p = r.o + t * r.d;
+    if (ob.kind == RTAMD_SPHERE) p = p - ld3(ob.p);
+    return p;
+}
+
+// ImageTexture.get_color through SphericalMap.get_texel_coordinates (texture.py:33-68).
+// Python raises where acos leaves its domain or the texel lies outside the image; here the
+// colour is NaN.
+__device__ __forceinline__ V3 texture_color(const rtamd_scene_desc& S, int tex, V3 local) {
+    const rtamd_texture& T = S.textures[tex];
+    const double theta = acos(local.y);
+    double phi = atan2(local.x, local.z);
+    if (phi < 0.) phi += PI * 2;
+    const double u = phi / PI / 2;
+    const double v = 1 - theta / PI;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    if (!(theta == theta)) return v3(nan, nan, nan);
+    const int column = (int)((T.hres - 1) * u);
+    const int row = (int)((T.vres - 1) * v);
+    if (column < 0 || column >= T.width || row < 0 || row >= T.height) return v3(nan, nan, nan);
+    const uint8_t* px = S.texels + T.offset + 3 * ((int64_t)row * T.width + column);
+    return v3(px[0] / 256., px[1] / 256., px[2] / 256.);
+}
+
 // The direct-lighting sum of Matte/Phong .shade and .area_light_shade (material.py:251-281,
 // :346-377) for every lane with `lit`; `area` selects the G/pdf weighting.  Lights are
 // visited in list order by the whole wave so that the shadow queries stay wave-wide.
-template <bool COUNT>
+// EXT: `tex` is the texture colour of an SV_Matte hit (material.py:311-326), which scales
+// ka and kd and adds the viewer-side test of :319.
+template <bool COUNT, bool EXT>
 __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, bool lit, const rtamd_material& m,
-                                const Hit& h, V3 wo, bool area, Draw& dr, Work<COUNT>& w) {
+                                const Hit& h, V3 wo, bool area, V3 tex, Draw& dr, Work<COUNT>& w) {
     // ambient_color.L(sr): AmbientLight (light.py:14-15) or AmbientOccluder (light.py:85-100)
     V3 amb = ld3(S.ambient.radiance);
     if (S.ambient.kind == RTAMD_AMBIENT_OCCLUDER) {
@@ -788,8 +819,9 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
         if (lit) sr.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
         if (occluded_wave<COUNT>(S, stk, lit, sr, false, 0.0, w)) amb = ld3(S.ambient.occluded);
     }
-    V3 L = ld3(m.ambient) * amb;
-    const bool phong = m.kind != RTAMD_MATTE;
+    const bool textured = EXT && m.kind == RTAMD_SV_MATTE;
+    V3 L = (textured ? ld3(m.ambient) * tex : ld3(m.ambient)) * amb;
+    const bool phong = m.kind != RTAMD_MATTE && !textured;
     // Matte.shade alone ignores receives_shadow (material.py:263 vs :279, :358, :374)
     const bool gate = (phong || area) ? (m.receives_shadow != 0) : true;
     for (int li = 0; li < S.n_lights; ++li) {
@@ -817,7 +849,7 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
             }
         }
         const double ndotwi = dot(h.n, wi);
-        const bool facing = lit && ndotwi > 0;
+        const bool facing = lit && ndotwi > 0 && !(textured && !(dot(h.n, wo) > 0.));
         bool in_shadow = false;
         if (lt.cast_shadow) {
             Ray sr;
@@ -831,6 +863,7 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
         }
         if (!facing || in_shadow || !gate) continue;
         V3 f = ld3(m.diffuse);
+        if (textured) f = (f * tex) / PI;                                                        // material.py:27-28
         if (phong) f = f + phong_lobe(ld3(m.specular), m.exp, h.n, wo, wi);
         V3 Ll = ld3(lt.radiance);
         if (lt.kind == RTAMD_POINT && lt.attenuation != 0)                                        // light.py:39-44
@@ -884,12 +917,13 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(pow(b.x, e), pow(
 // (product of the child weights so far) * local term.  Lanes whose path has ended stay in
 // the loop as helpers for the wave-wide kd leaf tests until every lane is done.
 //
-// BRANCH: the scene holds Transparent / Dielectric materials, whose two children per hit
+// EXT: the scene holds textured (SV_Matte) or two-child materials.  Transparent and
+// Dielectric spawn two children per hit
 // (material.py:428-436, :473-474) make the recursion a tree.  Each lane walks its tree
 // depth first in the reference's order - reflected subtree, then the refracted one - with
 // the waiting siblings in a per-lane list (one per level, RTAMD_MAX_BRANCH_LEVELS), so the
 // in-trace draw counter advances exactly as in the recursive formulation.
-template <bool COUNT, bool BRANCH>
+template <bool COUNT, bool EXT>
 __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, Primary& first) {
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
@@ -898,13 +932,13 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
     const bool area = S.tracer_kind == RTAMD_TRACER_AREA;
     first.object = -1; first.prim = -1; first.t = 0;
     bool primary = true;
-    PendingRay pending[BRANCH ? RTAMD_MAX_BRANCH_LEVELS : 1];
+    PendingRay pending[EXT ? RTAMD_MAX_BRANCH_LEVELS : 1];
     int n_pending = 0;
-    int lane_depth = depth;                 // BRANCH: lanes sit at different levels of their trees
+    int lane_depth = depth;                 // EXT: lanes sit at different levels of their trees
     V3 filter = v3(1, 1, 1);
     bool has_filter = false;
     for (;; ++depth, ++lane_depth) {
-        if (BRANCH) {
+        if (EXT) {
             if (!alive && n_pending > 0) {
                 const PendingRay& q = pending[--n_pending];
                 ray.o = q.o; ray.d = q.d; W = q.W; filter = q.filter;
@@ -923,7 +957,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
         if (alive && !hit) { L = L + W * background; alive = false; }
         if (alive && primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; }
         primary = false;
-        if (BRANCH && alive && has_filter) { W = W * powv(filter, h.t); has_filter = false; }
+        if (EXT && alive && has_filter) { W = W * powv(filter, h.t); has_filter = false; }
         const rtamd_material& m = S.materials[alive ? h.material : 0];
         const V3 wo = -ray.d;
 
@@ -954,7 +988,10 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
             continue;
         }
 
-        const V3 Ld = direct_light_wave<COUNT>(S, stk, alive, m, h, wo, area, dr, w);
+        V3 tex = v3(1, 1, 1);
+        if (EXT && alive && m.kind == RTAMD_SV_MATTE)
+            tex = texture_color(S, m.texture, local_hit_point(S.objects[h.object], ray, h.t));
+        const V3 Ld = direct_light_wave<COUNT, EXT>(S, stk, alive, m, h, wo, area, tex, dr, w);
         if (alive) L = L + W * Ld;
         if (area) { alive = false; continue; }
         if (!alive) continue;
@@ -986,7 +1023,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
             W = W * ((fr * dot(h.n, wi)) / pdf);
             ray.o = h.p;
             ray.d = wi;
-        } else if (BRANCH && m.kind == RTAMD_TRANSPARENT) {
+        } else if (EXT && m.kind == RTAMD_TRANSPARENT) {
             // PerfectSpecular.sample_f (material.py:69-74), PerfectTransmitter (:135-159),
             // Transparent.shade (:420-437)
             const double ndotwo = dot(h.n, wo);
@@ -1006,7 +1043,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
             }
             ray.o = h.p;
             ray.d = wi;
-        } else if (BRANCH && m.kind == RTAMD_DIELECTRIC) {
+        } else if (EXT && m.kind == RTAMD_DIELECTRIC) {
             // FresnelReflector.fresnel / sample_f (material.py:206-229), FresnelTransmitter
             // (:170-197), Dielectric.shade (:448-483)
             V3 nf;

@@ -70,10 +70,11 @@ __device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point,
     return r;
 }
 
-// BRANCH instantiations serve scenes with two-child materials (Transparent, Dielectric);
-// they keep a per-lane list of waiting child rays in private memory, which the other
-// instantiations do not pay for.
-template <int MODE, bool COUNT, bool BRANCH>
+// EXT instantiations serve scenes with two-child materials (Transparent, Dielectric) or
+// textured ones (SV_Matte); they keep a per-lane list of waiting child rays in private
+// memory and a texture colour across the shadow queries, which the other instantiations
+// do not pay for.
+template <int MODE, bool COUNT, bool EXT>
 __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
     // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         KdStack stk;
         stk.node = stack_node;
         stk.t = stack_t;
-        const V3 c = trace_wave<COUNT, BRANCH>(S, stk, live, ray, A.depth0, dr, work, first);
+        const V3 c = trace_wave<COUNT, EXT>(S, stk, live, ray, A.depth0, dr, work, first);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
             if (A.out.rgb) { A.out.rgb[3 * k] = c.x; A.out.rgb[3 * k + 1] = c.y; A.out.rgb[3 * k + 2] = c.z; }
@@ -210,7 +211,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 template <int MODE>
-int launch(const rtamd_scene_desc& S, bool branching, LaunchArgs& A, uint32_t flags, void* stream) {
+int launch(const rtamd_scene_desc& S, bool extended, LaunchArgs& A, uint32_t flags, void* stream) {
     if (A.n <= 0) return RTAMD_OK;
     A.seg_len = 0;
 #if RT_XCD_SEGMENTS > 0
@@ -225,7 +226,7 @@ int launch(const rtamd_scene_desc& S, bool branching, LaunchArgs& A, uint32_t fl
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool count = (flags & RTAMD_COUNT_WORK) != 0;
     const dim3 grid((unsigned)blocks), block(BLOCK);
-    if (branching) {
+    if (extended) {
         if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, true>), grid, block, 0, st, S, A);
         else hipLaunchKernelGGL((trace_kernel<MODE, false, true>), grid, block, 0, st, S, A);
     } else {
@@ -244,7 +245,8 @@ struct rtamd_scene {
     int device;
     rtamd_sampler* samplers_host;   // host copies of the small tables, for argument checks
     int max_tree_depth;
-    bool branching;                 // a Transparent / Dielectric material is traced recursively
+    bool extended;                  // two-child or textured materials: the EXT kernels run
+    bool two_child;                 // Transparent / Dielectric traced recursively
 };
 
 extern "C" {
@@ -289,7 +291,8 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
     s->desc = *d;
     s->device = dev;
     s->max_tree_depth = 0;
-    s->branching = false;
+    s->extended = false;
+    s->two_child = false;
     s->samplers_host = new (std::nothrow) rtamd_sampler[d->n_samplers];
     if (!s->samplers_host) { delete s; return fail(RTAMD_EINVAL, "out of host memory%s"); }
     e = hipMemcpy(s->samplers_host, d->samplers, sizeof(rtamd_sampler) * d->n_samplers, hipMemcpyDeviceToHost);
@@ -310,7 +313,19 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
         e = hipMemcpy(&m, d->materials + i, sizeof(m), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the material table"); }
         const bool draws = m.kind == RTAMD_GLOSSY_REFLECTIVE || (d->tracer_kind == RTAMD_TRACER_PATH && m.kind == RTAMD_MATTE);
-        if (m.kind < RTAMD_MATTE || m.kind > RTAMD_DIELECTRIC) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "unknown material kind%s"); }
+        if (m.kind < RTAMD_MATTE || m.kind > RTAMD_SV_MATTE) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "unknown material kind%s"); }
+        if (m.kind == RTAMD_SV_MATTE) {
+            // SV_Matte has shade() only (material.py:292-326)
+            if (d->tracer_kind == RTAMD_TRACER_AREA || d->tracer_kind == RTAMD_TRACER_PATH) {
+                rtamd_scene_destroy(s);
+                return fail(RTAMD_EUNSUPPORTED, "an SV_Matte material needs the shade or Whitted tracer%s");
+            }
+            if (m.texture < 0 || m.texture >= d->n_textures) {
+                rtamd_scene_destroy(s);
+                return fail(RTAMD_EINVAL, "a textured material refers to a texture outside the table%s");
+            }
+            s->extended = true;
+        }
         const bool two_children = m.kind == RTAMD_TRANSPARENT || m.kind == RTAMD_DIELECTRIC;
         if (two_children && d->tracer_kind != RTAMD_TRACER_AREA) {
             // Dielectric.shade hands trace_ray a third argument (material.py:459); only
@@ -323,7 +338,8 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
                 rtamd_scene_destroy(s);
                 return fail(RTAMD_EUNSUPPORTED, "depth limit too large for two-child materials%s");
             }
-            s->branching = true;
+            s->extended = true;
+            s->two_child = true;
         }
         if (d->tracer_kind == RTAMD_TRACER_PATH && m.kind != RTAMD_MATTE && m.kind != RTAMD_EMISSIVE) {
             rtamd_scene_destroy(s);
@@ -333,6 +349,21 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
             rtamd_scene_destroy(s);
             return fail(RTAMD_EINVAL, "a material that samples a lobe has no sampler%s");
         }
+    }
+    if (d->n_textures < 0 || (d->n_textures && (!d->textures || !d->texels))) {
+        rtamd_scene_destroy(s);
+        return fail(RTAMD_EINVAL, "texture tables missing%s");
+    }
+    for (int i = 0; i < d->n_textures; ++i) {
+        rtamd_texture t;
+        e = hipMemcpy(&t, d->textures + i, sizeof(t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the texture table"); }
+        if (t.width < 1 || t.height < 1 || t.hres < 1 || t.vres < 1 || t.hres > t.width || t.vres > t.height ||
+            t.offset < 0 || t.offset + 3 * (int64_t)t.width * t.height > d->n_texel_bytes) {
+            rtamd_scene_destroy(s);
+            return fail(RTAMD_EINVAL, "a texture lies outside texels or has bad extents%s");
+        }
+        if (t.mapping != RTAMD_MAP_SPHERICAL) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "unknown texture mapping%s"); }
     }
     for (int i = 0; i < d->n_lights; ++i) {
         rtamd_light l;
@@ -403,7 +434,7 @@ int rtamd_render_pixels(rtamd_scene* scene, const rtamd_camera* camera, uint64_t
     A.b3 = lens_points;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_PIXELS>(scene->desc, scene->branching, A, flags, stream);
+    return launch<MODE_PIXELS>(scene->desc, scene->extended, A, flags, stream);
 }
 
 int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t* pixel_index,
@@ -414,7 +445,7 @@ int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t
     if (n < 0) return fail(RTAMD_EINVAL, "negative ray count%s");
     if (n == 0) return RTAMD_OK;
     if (!origins || !directions || !out) return fail(RTAMD_EINVAL, "null ray buffer%s");
-    if (scene->branching && depth < 0) return fail(RTAMD_EINVAL, "negative start depth in a scene with two-child materials%s");
+    if (scene->two_child && depth < 0) return fail(RTAMD_EINVAL, "negative start depth in a scene with two-child materials%s");
     LaunchArgs A;
     memset(&A, 0, sizeof(A));
     A.trace_key = phase_key(seed, PHASE_TRACE);
@@ -427,7 +458,7 @@ int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t
     A.depth0 = depth;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_RAYS>(scene->desc, scene->branching, A, flags, stream);
+    return launch<MODE_RAYS>(scene->desc, scene->extended, A, flags, stream);
 }
 
 int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t seed, int64_t n_tiles,
@@ -455,7 +486,7 @@ int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t 
     A.sum_rgb8 = sum_rgb8;
     A.sum_sq = sum_sq;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_TILES>(scene->desc, scene->branching, A, flags, stream);
+    return launch<MODE_TILES>(scene->desc, scene->extended, A, flags, stream);
 }
 
 }  // extern "C"

@@ -31,7 +31,7 @@ class FlatScene(object):
 
     TABLES = ("objects", "materials", "lights", "samplers", "sampler_data", "trees",
               "kd_nodes", "tri_geom", "tri_prim", "prim_normals", "prim_normal_offset",
-              "prim_material")
+              "prim_material", "textures", "texels")
 
     def __init__(self):
         self.arrays = {}
@@ -61,6 +61,8 @@ class FlatScene(object):
         d.n_refs = len(a["tri_prim"])
         d.n_prims = len(a["prim_material"])
         d.n_sampler_doubles = len(a["sampler_data"])
+        d.n_textures = len(a["textures"]) // C.sizeof(capi.Texture)
+        d.n_texel_bytes = len(a["texels"])
         d.background[:] = list(self.background)
         d.ambient = self.ambient
         for name in self.TABLES:
@@ -83,6 +85,7 @@ class _Flattener(object):
         self.world = world
         self.samplers, self.sampler_ids = [], {}
         self.materials, self.material_ids = [], {}
+        self.textures, self.texture_ids, self.texels, self.n_texel_bytes = [], {}, [], 0
         self.trees = []
         self.kd_nodes = []
         self.tri_geom, self.tri_prim = [], []
@@ -101,6 +104,24 @@ class _Flattener(object):
             self.samplers.append(sampler)
         return self.sampler_ids[key]
 
+    def texture_id(self, texture):
+        if texture is None:
+            return -1
+        key = id(texture)
+        if key not in self.texture_ids:
+            rec = texture.device_record()
+            pixels = numpy.ascontiguousarray(rec["pixels"], dtype=numpy.uint8)
+            t = capi.Texture()
+            t.height, t.width = pixels.shape[:2]
+            t.hres, t.vres = rec["hres"], rec["vres"]
+            t.mapping = rec["mapping"]
+            t.offset = self.n_texel_bytes
+            self.texels.append(pixels.reshape(-1))
+            self.n_texel_bytes += pixels.size
+            self.texture_ids[key] = len(self.textures)
+            self.textures.append(t)
+        return self.texture_ids[key]
+
     def material_id(self, material):
         if material is None:
             raise ValueError("an object in the scene has no material")
@@ -111,6 +132,7 @@ class _Flattener(object):
             m.kind = rec["kind"]
             m.receives_shadow = int(bool(rec.get("receives_shadow", True)))
             m.sampler = self.sampler_id(rec.get("sampler"))
+            m.texture = self.texture_id(rec.get("texture"))
             for field in ("ambient", "diffuse", "specular", "reflect", "emit", "filter_in", "filter_out"):
                 if field in rec:
                     _fill(getattr(m, field), rec[field])
@@ -330,6 +352,9 @@ def flatten_world(world):
                 and scene.depth_limit + 1 > capi.MAX_BRANCH_LEVELS):
             raise NotImplementedError("two-child materials are traced to depth_limit <= %d on the device"
                                       % (capi.MAX_BRANCH_LEVELS - 1))
+        if m.kind == M.SV_MATTE and scene.tracer_kind in (capi.TRACER_AREA, capi.TRACER_PATH):
+            # SV_Matte has neither area_light_shade nor path_shade (material.py:292-326)
+            raise AttributeError("SV_Matte only has shade(): it needs a Tracer or a WhittedTracer")
         samples_lobe = m.kind == M.GLOSSY_REFLECTIVE or (scene.tracer_kind == capi.TRACER_PATH and m.kind == M.MATTE)
         if samples_lobe and m.sampler < 0:
             # the reference fails here too: `None.sample_unit_hemisphere_surface` (material.py:47, :110)
@@ -356,6 +381,8 @@ def flatten_world(world):
     a["prim_normals"] = _cat(fl.prim_normals, numpy.float64)
     a["prim_normal_offset"] = _cat(fl.prim_normal_offset, numpy.int64)
     a["prim_material"] = _cat(fl.prim_material, numpy.int32)
+    a["textures"] = pack(fl.textures, capi.Texture)
+    a["texels"] = _cat(fl.texels, numpy.uint8)
     scene.sampler_objects = fl.samplers
     scene.n_trees = len(fl.trees)
     return scene

@@ -136,11 +136,20 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
 
 
 def test_unsupported_scene_features_are_refused():
-    import material, tracer
-    with pytest.raises(NotImplementedError):
-        material.SV_Matte().device_record()
+    import material, texture, tracer
     from raytracer_amd import flatten
     from raytracer_amd.world import World
+    # a texture without a mapping reads (u, v) that no hit record has (texture.py:42-43)
+    with pytest.raises(AttributeError):
+        texture.ImageTexture(numpy.zeros((4, 4, 3), numpy.uint8), None, None).device_record()
+    with pytest.raises(IndexError):
+        texture.ImageTexture(numpy.zeros((4, 4, 3), numpy.uint8), None, texture.SphericalMap(), hres=8, vres=4).device_record()
+    # SV_Matte has shade() only: no area-light or path tracer (material.py:292-326)
+    world = World(viewmode="realtime", buildfunction="features_texture")
+    assert flatten.flatten_world(world).arrays["texels"].size == 96 * 48 * 3 + 40 * 30 * 3
+    world.tracer = tracer.AreaLightTracer(world)
+    with pytest.raises(AttributeError):
+        flatten.flatten_world(world)
     # Dielectric.shade needs the three-argument trace_ray that only WhittedTracer has
     world = World(viewmode="realtime", buildfunction="features_glass")
     flatten.flatten_world(world)
@@ -212,3 +221,24 @@ def test_reference_scene_files_load_unchanged(name, twin):
         for key in flat.arrays:
             assert numpy.array_equal(flat.arrays[key], ours.arrays[key]), key
         assert flat.tracer_kind == ours.tracer_kind and flat.depth_limit == ours.depth_limit
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_SCENES), reason="the reference tree is only present in the build container")
+def test_reference_earth_scene_builds_with_a_supplied_image():
+    """buildfunctions/earth.py names an image the reference does not ship
+    (textures/earth_8k.jpg); the scene file itself builds unchanged, and flattens once
+    an image is supplied."""
+    import raytracer_amd
+    from raytracer_amd import flatten, rng
+    from raytracer_amd.world import World, load_scene_file
+    module = load_scene_file(os.path.join(REFERENCE_SCENES, "earth.py"))
+    world = World.__new__(World)
+    world.seed = 1
+    rng.context.reseed(1)
+    module.BuildFunction.build_function(world, "realtime")
+    with pytest.raises(FileNotFoundError):
+        flatten.flatten_world(world)
+    tex = world.objects[0].material.diffuse_brdf.cd
+    tex.image = numpy.arange(16 * 8 * 3, dtype=numpy.uint8).reshape(8, 16, 3)
+    flat = flatten.flatten_world(world)
+    assert flat.arrays["texels"].size == 16 * 8 * 3
