@@ -132,6 +132,33 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
 __device__ __forceinline__ int first_lane(unsigned long long mask) {
     return __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mask));
 }
+// Bit patterns of floats that bracket a non-negative double from below / above (the bit
+// patterns of non-negative floats order like the values).
+__device__ __forceinline__ uint32_t float_bits_below(double x) {
+    if (!(x > 0.0)) return 0u;
+    const float f = (float)x;
+    uint32_t b = __float_as_uint(f);
+    if ((double)f > x) b -= 1u;
+    return b;
+}
+__device__ __forceinline__ uint32_t float_bits_above(double x) {
+    const float f = (float)x;
+    uint32_t b = __float_as_uint(f);
+    if ((double)f < x) b += 1u;
+    return b;
+}
+// Minimum of a 32-bit value over the 64 lanes (all active), wave-uniform result: two
+// quad permutes and two row rotations leave every lane with the minimum of its row of 16,
+// the four rows are combined on the scalar side.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, true));   // row_ror:4
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, true));   // row_ror:8
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
 
 // ---------------------------------------------------------------- triangles
 // geometry.py:447-455 solves [v1-v0, v2-v0, -d] (alpha, beta, t)^T = o - v0 with LAPACK.
@@ -185,6 +212,34 @@ __device__ __forceinline__ bool tri_solve_ref(const TriTable& tt, int32_t ref, c
     const V3 e2 = v3(tri_component(tt, off, 6), tri_component(tt, off, 7), tri_component(tt, off, 8));
     return tri_solve_v(v0, e1, e2, r, alpha, beta, t);
 }
+
+// ---------------------------------------------------------------- phase timers (profiling builds)
+// With RT_PHASE_TIMERS every wave adds the shader-clock cycles it spends in each part of a
+// kd query to a global table (closest-hit queries in slots 0-7, shadow queries in 8-15,
+// whole waves in slot 16); tools/phase_profile.py builds such a library and prints the split.
+#ifdef RT_PHASE_TIMERS
+__device__ unsigned long long g_phase_cycles[32];
+struct PhaseClock {
+    long long last;
+    int base;
+    __device__ __forceinline__ void start(int b) { base = b; last = clock64(); }
+    __device__ __forceinline__ void lap(int slot) {
+        const long long now = clock64();
+        if (lane_id() == 0) atomicAdd(&g_phase_cycles[base + slot], (unsigned long long)(now - last));
+        last = clock64();
+    }
+    __device__ __forceinline__ void count(int slot) {
+        if (lane_id() == 0) atomicAdd(&g_phase_cycles[base + slot], 1ull);
+    }
+};
+#else
+struct PhaseClock {
+    __device__ __forceinline__ void start(int) {}
+    __device__ __forceinline__ void lap(int) {}
+    __device__ __forceinline__ void count(int) {}
+};
+#endif
+enum { PH_DESCENT = 0, PH_PACK16 = 1, PH_PACK32 = 2, PH_BIG_PLAIN = 3, PH_BIG_BOXES = 4, PH_POP = 5, PH_QUERIES = 6 };
 
 // ---------------------------------------------------------------- kd-tree
 // Traversal stack of one wave.  An entry is (far child, t at the split plane); the far
@@ -320,7 +375,7 @@ __device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, unsigne
 // leaf order that reports a hit ends the query and its t is returned.
 template <bool COUNT, bool SHADOW>
 __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool active, const Ray& r,
-                              const KdStack& stk, Work<COUNT>& w, bool& found, TriHit& best) {
+                              double limit, const KdStack& stk, Work<COUNT>& w, bool& found, TriHit& best) {
     found = false;
     double t_near = 0, t_far = 0, t_exit = 0;
     bool walking = active && root_box(T, r, t_near, t_exit);
@@ -331,6 +386,9 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     int32_t node = T.node_offset;
     const int lane = lane_id();
     const TriTable geom = tri_table(S);
+    PhaseClock clk;
+    clk.start(SHADOW ? 8 : 0);
+    clk.count(PH_QUERIES);
 
     while (__ballot(walking)) {
         int32_t first = 0, count = 0, cbase = -1;
@@ -363,6 +421,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
             cbase = S.chunk_boxes ? (int32_t)nd.split : -1;
         }
 
+        clk.lap(PH_DESCENT);
         const bool small = walking && count <= SMALL_LEAF;
         if (small) {
             if (SHADOW) {
@@ -389,7 +448,9 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         const bool pack32 = walking && !small && !pack16 && count <= 32;
         const unsigned long long p16 = __ballot(pack16), p32 = __ballot(pack32);
         if (p16) packed_leaves<COUNT, SHADOW, 16>(S, p16, r, first, count, w, found, best);
+        clk.lap(PH_PACK16);
         if (p32) packed_leaves<COUNT, SHADOW, 32>(S, p32, r, first, count, w, found, best);
+        clk.lap(PH_PACK32);
 
         unsigned long long big = __ballot(walking && !small && count > 32);
         while (big) {
@@ -434,28 +495,61 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
 
             if (qbox >= 0) {
                 // leaf with chunk boxes: lane j tests the box of chunk j against the ray's line,
-                // then the wave visits only the chunks whose box the line touches
+                // then the wave visits only chunks that can still matter:
+                //  * closest hit: nearest box first; a chunk whose box the ray enters beyond
+                //    the best t so far cannot hold a closer (or equal) hit and is dropped;
+                //  * shadow: when every touched box ends before `limit` (always, without a
+                //    limit) any hit decides the query the same way as the first one in scan
+                //    order would (light.py:34-35, :127-128), so the first chunk with a hit
+                //    ends it; otherwise all touched chunks are scanned for the earliest item.
                 const double ix = 1.0 / q.d.x, iy = 1.0 / q.d.y, iz = 1.0 / q.d.z;
                 const double* __restrict__ cb = S.chunk_boxes;
                 const int64_t nc = S.n_chunks;
-                for (int32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+                const double qlimit = SHADOW ? bcast_d(limit, src) : 0.0;
+                uint32_t bound = 0x7f800000u;          // float bits of an upper bound of the best t (closest)
+                for (int32_t c0 = 0; c0 < n_chunks && !stop; c0 += 64) {
                     const int32_t j = c0 + lane;
                     bool touch = false;
+                    double tn = 0, tf = 0;
                     if (j < n_chunks) {
                         const double* bx = cb + qbox + j;
                         const double x0 = (bx[0] - q.o.x) * ix, x1 = (bx[3 * nc] - q.o.x) * ix;
                         const double y0 = (bx[nc] - q.o.y) * iy, y1 = (bx[4 * nc] - q.o.y) * iy;
                         const double z0 = (bx[2 * nc] - q.o.z) * iz, z1 = (bx[5 * nc] - q.o.z) * iz;
                         // fmin/fmax drop NaNs (0*inf on a slab boundary), which keeps the test conservative
-                        const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
-                        const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+                        tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+                        tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
                         touch = !(tn > tf) && !(tf < 0.0);
                     }
-                    unsigned long long todo = __ballot(touch);
-                    while (todo) {
-                        const int32_t c = (c0 + first_lane(todo)) << 6;
-                        todo &= todo - 1;
-                        test_chunk(c);
+                    if (!SHADOW) {
+                        // key = float lower bound of the entry distance (6 low bits give way to
+                        // the lane number), so the wave minimum names the nearest chunk
+                        uint32_t key = 0xFFFFFFFFu;
+                        if (touch) key = (float_bits_below(tn) & ~63u) | (uint32_t)lane;
+                        for (;;) {
+                            if (key != 0xFFFFFFFFu && (key & ~63u) > bound) key = 0xFFFFFFFFu;
+                            const uint32_t kmin = wave_min_u32(key);
+                            if (kmin == 0xFFFFFFFFu) break;
+                            const int jl = (int)(kmin & 63u);
+                            if (lane == jl) key = 0xFFFFFFFFu;
+                            const bool before = lfound;
+                            const double t_before = lt;
+                            test_chunk((c0 + jl) << 6);
+                            const bool improved = lfound && (!before || lt < t_before);
+                            if (__ballot(improved)) {
+                                const uint32_t up = lfound ? float_bits_above(lt) : 0x7f800000u;
+                                bound = wave_min_u32(up);
+                            }
+                        }
+                    } else {
+                        unsigned long long todo = __ballot(touch);
+                        const bool any_hit_decides = !COUNT && n_chunks <= 64 && !__ballot(touch && !(tf < qlimit));
+                        while (todo) {
+                            const int32_t c = (c0 + first_lane(todo)) << 6;
+                            todo &= todo - 1;
+                            test_chunk(c);
+                            if (any_hit_decides && __ballot(lfound)) { stop = true; break; }
+                        }
                     }
                 }
             } else {
@@ -500,6 +594,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 }
             }
             if (lane == src) w.tri(SHADOW ? tests : (uint32_t)qcount);
+            clk.lap(qbox >= 0 ? PH_BIG_BOXES : PH_BIG_PLAIN);
         }
 
         if (walking) {
@@ -515,6 +610,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 else t_far = deep_t[sp - 1 - LDS_STACK];
             }
         }
+        clk.lap(PH_POP);
     }
 }
 
@@ -645,7 +741,7 @@ __device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, 
                 const rtamd_tree& T = S.trees[ob.tree];
                 TriHit th;
                 bool f;
-                kd_query_wave<COUNT, false>(S, T, active, r, stk, w, f, th);
+                kd_query_wave<COUNT, false>(S, T, active, r, 0.0, stk, w, f, th);
                 if (active && f) {
                     hit = true;
                     t = th.t;
@@ -728,7 +824,7 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
             if (__ballot(q)) {
                 TriHit th;
                 bool f;
-                kd_query_wave<COUNT, true>(S, S.trees[ob.tree], q, r, stk, w, f, th);
+                kd_query_wave<COUNT, true>(S, S.trees[ob.tree], q, r, use_limit ? limit : T_INF * 4.0, stk, w, f, th);
                 hit = q && f;
                 t = th.t;
             }

@@ -81,6 +81,9 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
     // work list is cut into RT_XCD_SEGMENTS contiguous segments and segment j is given to
     // the workgroups of XCD j % 8, so each L2 serves a few bands of the frame instead of
     // every tile; A.seg_len == 0 keeps the identity order.
+#ifdef RT_PHASE_TIMERS
+    const long long wave_start = clock64();
+#endif
     int64_t wave = blockIdx.x;
     if (MODE == MODE_TILES && A.seg_len > 0) {
         const int64_t x = wave & 7, i = wave >> 3;
@@ -181,6 +184,12 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         }
     }
 
+#ifdef RT_PHASE_TIMERS
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_phase_cycles[16], (unsigned long long)(clock64() - wave_start));
+        atomicAdd(&g_phase_cycles[17], 1ull);
+    }
+#endif
     if (A.counters) {
         // one add per counter per block
         __shared__ unsigned int blk[RTAMD_N_COUNTERS];
@@ -252,6 +261,20 @@ struct rtamd_scene {
 extern "C" {
 
 int rtamd_abi_version(void) { return RTAMD_ABI_VERSION; }
+
+#ifdef RT_PHASE_TIMERS
+// profiling builds only: read (and clear) the per-phase cycle table
+int rtamd_debug_phase_cycles(unsigned long long* out32, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(rt::g_phase_cycles), 32 * sizeof(unsigned long long));
+    if (e != hipSuccess) return hip_fail(e, "reading the phase table");
+    if (reset) {
+        unsigned long long zero[32] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(rt::g_phase_cycles), zero, sizeof(zero));
+        if (e != hipSuccess) return hip_fail(e, "clearing the phase table");
+    }
+    return RTAMD_OK;
+}
+#endif
 
 const char* rtamd_last_error(void) { return g_error; }
 

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Where the waves of the tile kernel spend their cycles.
+
+Builds raytracer_amd/csrc/librtamd_phases.so (the product sources with RT_PHASE_TIMERS:
+every wave adds its shader-clock cycles per part of a kd query to a table), renders frames
+of a bench workload with it and prints the split.  Measurement tool, not part of the
+product; the timed library is the normal build.
+
+  python tools/phase_profile.py --build          (in the build container)
+  python tools/phase_profile.py [--workload W]   (on the GPU box)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+LIB = os.path.join(REPO, "raytracer_amd", "csrc", "librtamd_phases.so")
+NAMES = ["descent", "pack16", "pack32", "big_plain", "big_boxes", "pop", "queries", "-"]
+
+
+def build():
+    import __graft_entry__ as entry
+    src = os.path.join(REPO, "raytracer_amd", "csrc", "rt_kernels.hip")
+    cmd = ["/opt/rocm/bin/hipcc"] + entry.HIP_FLAGS + ["-DRT_PHASE_TIMERS", "-I", os.path.join(REPO, "include"), src, "-o", LIB]
+    subprocess.check_call(cmd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--workload", default="dragon_1080p_16spp_ao_arealight")
+    ap.add_argument("--frames", type=int, default=2)
+    args = ap.parse_args()
+    if args.build:
+        build()
+        return
+    os.environ["RTAMD_LIB"] = LIB
+    import torch
+    import bench
+    from raytracer_amd import capi, distributed, flatten, runtime
+    from raytracer_amd.world import World
+    scene, overrides = bench.WORKLOADS[args.workload]
+    world = World.__new__(World)
+    if overrides:
+        world.overrides = overrides
+    World.__init__(world, viewmode="parallel", buildfunction=scene, seed=1)
+    job = distributed.FrameJob(world, 0, 1)
+    lib = capi.library()
+    table = (C.c_ulonglong * 32)()
+    job.render()
+    torch.cuda.synchronize()
+    lib.rtamd_debug_phase_cycles(table, 1)
+    for _ in range(args.frames):
+        job.render()
+    torch.cuda.synchronize()
+    lib.rtamd_debug_phase_cycles(table, 1)
+    t = [int(x) for x in table]
+    total, waves = t[16], t[17]
+    out = {"workload": args.workload, "frames": args.frames, "waves": waves, "cycles_per_wave": total / max(waves, 1)}
+    for base, kind in ((0, "closest"), (8, "shadow")):
+        for i, name in enumerate(NAMES[:6]):
+            out["%s_%s" % (kind, name)] = t[base + i] / float(total)
+        out["%s_queries_per_wave" % kind] = t[base + 6] / float(max(waves, 1))
+    out["outside_kd_queries"] = 1.0 - sum(t[0:6] + t[8:14]) / float(total)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
