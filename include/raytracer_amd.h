@@ -187,8 +187,12 @@ typedef struct rtamd_tree {
     int32_t prim_offset;    /* first primitive of this tree in prim_* arrays       */
     int32_t smooth;         /* vertex normals present: prim_normals holds 9/prim   */
     int32_t depth;          /* maximum node depth (stack bound)                    */
-    int32_t reserved[3];
+    int32_t shadow_casters; /* what bit 30 of this tree's tri_prim rows says, in one word:
+                               RTAMD_CASTERS_ALL (no row has it), _NONE (every row has it:
+                               a mesh with cast_shadow off, geometry.py:433-434) or _MIXED */
+    int32_t reserved[2];
 } rtamd_tree;
+enum { RTAMD_CASTERS_ALL = 0, RTAMD_CASTERS_NONE = 1, RTAMD_CASTERS_MIXED = 2 };
 
 /* An ImageTexture (texture.py:11-46): 8-bit RGB texels, row-major from the top row as
  * PIL's getpixel((column, row)) addresses them, at texels[offset + 3*(row*width + column)].
@@ -217,6 +221,12 @@ typedef struct rtamd_texture {
  *   chunk_boxes[6][n_chunks] = lo.xyz, hi.xyz of each 64-row chunk of the leaves that carry
  *                       boxes (conservative: every triangle of the chunk lies inside);
  *                       may be NULL with n_chunks = 0
+ *   leaf_boxes[n_chunks][9][6] = the same chunk box followed by the boxes of the chunk's eight
+ *                       8-row cells (unused cells zero), and
+ *   tri_rows[n_refs][10] = row-major copy of tri_geom with {tri_prim, tri_order} packed into
+ *                       the tenth double: what a single lane reads when it scans a boxed
+ *                       leaf for its own ray.  Both optional (NULL: the wave scans such
+ *                       leaves together, chunk by chunk).
  * Per-primitive tables (one row per triangle, all trees concatenated):
  *   prim_normals      = unit face normal [3], or n0,n1,n2 [9] for smooth trees; rows
  *                       are addressed through prim_normal_offset[prim] (in doubles)
@@ -248,6 +258,11 @@ typedef struct rtamd_scene_desc {
     const double *tri_geom;             /* device */
     const int32_t *tri_prim;            /* device */
     const int32_t *tri_order;           /* device, optional */
+    const double *tri_rows;             /* device, optional: [n_refs][10] row-major copy of tri_geom,
+                                           tenth double = {tri_prim, tri_order} as two int32 */
+    const double *leaf_boxes;           /* device, optional: [n_chunks][9][6] = per chunk its own
+                                           box (as chunk_boxes) and the boxes of its eight
+                                           8-row cells, lo.xyz hi.xyz each */
     const double *chunk_boxes;          /* device, optional */
     const double *prim_normals;         /* device */
     const int64_t *prim_normal_offset;  /* device */

@@ -13,6 +13,7 @@ N_COUNTERS = 8
 COUNT_WORK = 1
 
 SPHERE, PLANE, CHECKER_PLANE, RECTANGLE, BOX, TRIANGLE, KDTREE = range(7)
+CASTERS_ALL, CASTERS_NONE, CASTERS_MIXED = range(3)
 TRACER_SHADE, TRACER_AREA, TRACER_PATH, TRACER_WHITTED = range(4)
 
 d3 = C.c_double * 3
@@ -59,7 +60,7 @@ class KdNode(C.Structure):
 class Tree(C.Structure):
     _fields_ = [("bbox_lo", d3), ("bbox_hi", d3), ("node_offset", C.c_int32),
                 ("ref_offset", C.c_int32), ("prim_offset", C.c_int32), ("smooth", C.c_int32),
-                ("depth", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("depth", C.c_int32), ("shadow_casters", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Texture(C.Structure):
@@ -77,7 +78,7 @@ class SceneDesc(C.Structure):
                 ("objects", C.c_void_p), ("materials", C.c_void_p), ("lights", C.c_void_p),
                 ("samplers", C.c_void_p), ("sampler_data", C.c_void_p), ("trees", C.c_void_p),
                 ("kd_nodes", C.c_void_p), ("tri_geom", C.c_void_p), ("tri_prim", C.c_void_p),
-                ("tri_order", C.c_void_p), ("chunk_boxes", C.c_void_p),
+                ("tri_order", C.c_void_p), ("tri_rows", C.c_void_p), ("leaf_boxes", C.c_void_p), ("chunk_boxes", C.c_void_p),
                 ("prim_normals", C.c_void_p), ("prim_normal_offset", C.c_void_p),
                 ("prim_material", C.c_void_p),
                 ("n_textures", C.c_int32), ("reserved", C.c_int32), ("n_texel_bytes", C.c_int64),

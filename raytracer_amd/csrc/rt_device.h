@@ -132,34 +132,6 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
 __device__ __forceinline__ int first_lane(unsigned long long mask) {
     return __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mask));
 }
-// Bit patterns of floats that bracket a non-negative double from below / above (the bit
-// patterns of non-negative floats order like the values).
-__device__ __forceinline__ uint32_t float_bits_below(double x) {
-    if (!(x > 0.0)) return 0u;
-    const float f = (float)x;
-    uint32_t b = __float_as_uint(f);
-    if ((double)f > x) b -= 1u;
-    return b;
-}
-__device__ __forceinline__ uint32_t float_bits_above(double x) {
-    const float f = (float)x;
-    uint32_t b = __float_as_uint(f);
-    if ((double)f < x) b += 1u;
-    return b;
-}
-// Minimum of a 32-bit value over the 64 lanes (all active), wave-uniform result: two
-// quad permutes and two row rotations leave every lane with the minimum of its row of 16,
-// the four rows are combined on the scalar side.
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, true));   // row_ror:4
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, true));   // row_ror:8
-    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
-    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-    return min(min(a, b), min(c, d));
-}
-
 // ---------------------------------------------------------------- triangles
 // geometry.py:447-455 solves [v1-v0, v2-v0, -d] (alpha, beta, t)^T = o - v0 with LAPACK.
 // Here the same system is solved by Cramer's rule in the Moeller-Trumbore arrangement;
@@ -211,6 +183,22 @@ __device__ __forceinline__ bool tri_solve_ref(const TriTable& tt, int32_t ref, c
     const V3 e1 = v3(tri_component(tt, off, 3), tri_component(tt, off, 4), tri_component(tt, off, 5));
     const V3 e2 = v3(tri_component(tt, off, 6), tri_component(tt, off, 7), tri_component(tt, off, 8));
     return tri_solve_v(v0, e1, e2, r, alpha, beta, t);
+}
+
+// Row-major copy of the triangle table for scans by a single lane: one row = 80 contiguous
+// bytes (v0, e1, e2 and {tri_prim, tri_order}), five 16-byte loads.
+struct TriRow { V3 v0, e1, e2; int32_t prim, order; };
+__device__ __forceinline__ TriRow load_row(const rtamd_scene_desc& S, int32_t ref) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* p = reinterpret_cast<const d2*>(S.tri_rows + (int64_t)ref * 10);
+    const d2 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    TriRow r;
+    r.v0 = v3(a.x, a.y, b.x);
+    r.e1 = v3(b.y, c.x, c.y);
+    r.e2 = v3(d.x, d.y, e.x);
+    r.prim = __double2loint(e.y);
+    r.order = __double2hiint(e.y);
+    return r;
 }
 
 // ---------------------------------------------------------------- phase timers (profiling builds)
@@ -279,9 +267,9 @@ struct TriHit { double t, alpha, beta; int32_t ref; };
 // lane then collects its group's result.  Rows of such leaves are stored in scan order,
 // so the scan position of a row is its lane's position in the group.
 template <bool COUNT, bool SHADOW, int W>
-__device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, unsigned long long pending, const Ray& r,
-                                              int32_t first, int32_t count, Work<COUNT>& w, bool& found,
-                                              TriHit& best) {
+__device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, bool flagged, unsigned long long pending,
+                                              const Ray& r, int32_t first, int32_t count, Work<COUNT>& w,
+                                              bool& found, TriHit& best) {
     constexpr int R = 64 / W;
     const int lane = lane_id();
     const int grp = lane / W, sub = lane % W;
@@ -307,7 +295,7 @@ __device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, unsigne
         const bool in = sub < qcount;
         const int32_t ref = qfirst + (in ? sub : 0);
         bool usable = in;
-        if (SHADOW) usable = in && !(S.tri_prim[ref] & NO_SHADOW_BIT);                    // geometry.py:433-434
+        if (SHADOW && flagged) usable = in && !(S.tri_prim[ref] & NO_SHADOW_BIT);         // geometry.py:433-434
         double a = 0, b = 0, t = 0;
         const bool hit = usable && tri_solve_ref(geom, ref, q, a, b, t);
         const unsigned long long hm = __ballot(hit);
@@ -362,6 +350,52 @@ __device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, unsigne
     }
 }
 
+// Slab test of a box given as lo.xyz, hi.xyz (six contiguous doubles) against the ray's
+// line; conservative (fmin/fmax drop the NaNs of 0*inf on a slab boundary).  tn = entry
+// distance.
+__device__ __forceinline__ bool box_touch(const double* bx, const Ray& q, V3 inv, double& tn) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* p = reinterpret_cast<const d2*>(bx);
+    const d2 a = p[0], b = p[1], c = p[2];          // lo.x lo.y | lo.z hi.x | hi.y hi.z
+    const double x0 = (a.x - q.o.x) * inv.x, x1 = (b.y - q.o.x) * inv.x;
+    const double y0 = (a.y - q.o.y) * inv.y, y1 = (c.x - q.o.y) * inv.y;
+    const double z0 = (b.x - q.o.z) * inv.z, z1 = (c.y - q.o.z) * inv.z;
+    tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+    const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+    return !(tn > tf) && !(tf < 0.0);
+}
+
+// KDTree.hit's scan of one boxed leaf (kdtree.py:169-173) by the lane that owns the ray:
+// chunk boxes, then the boxes of a touched chunk's 8-row cells, then the rows of a touched
+// cell.  A box the ray enters beyond the best t so far cannot hold a closer or equal hit.
+// Meant for waves whose rays are close together (primary rays of a tile): their lanes read
+// the same boxes and rows, so the loads coalesce.
+__device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& S, const Ray& r, int32_t first,
+                                                        int32_t count, int32_t cbase, bool& found, TriHit& best) {
+    const V3 inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    const int32_t n_chunks = (count + 63) >> 6;
+    int32_t best_ord = 0;
+    for (int32_t j = 0; j < n_chunks; ++j) {
+        const double* rec = S.leaf_boxes + (int64_t)(cbase + j) * 54;
+        double tn;
+        if (!box_touch(rec, r, inv, tn) || (found && tn > best.t)) continue;
+        const int32_t rows_here = min(64, count - (j << 6));
+        for (int32_t k = 0; k * 8 < rows_here; ++k) {
+            if (!box_touch(rec + 6 * (1 + k), r, inv, tn) || (found && tn > best.t)) continue;
+            const int32_t r0 = first + (j << 6) + k * 8;
+            const int32_t nr = min(8, rows_here - k * 8);
+            for (int32_t i = 0; i < nr; ++i) {
+                const TriRow row = load_row(S, r0 + i);
+                double a, b, t;
+                if (tri_solve_v(row.v0, row.e1, row.e2, r, a, b, t) &&
+                    (!found || t < best.t || (t == best.t && row.order < best_ord))) {
+                    best.t = t; best.alpha = a; best.beta = b; best.ref = r0 + i; best_ord = row.order; found = true;
+                }
+            }
+        }
+    }
+}
+
 // One kd-tree query per active lane, all 64 lanes inside.
 //
 // Each lane walks the tree front to back exactly as KDTree.iterate_nodes does
@@ -377,6 +411,12 @@ template <bool COUNT, bool SHADOW>
 __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool active, const Ray& r,
                               double limit, const KdStack& stk, Work<COUNT>& w, bool& found, TriHit& best) {
     found = false;
+    // rows carry a does-not-cast-shadows bit; the tree says whether any row has it, so
+    // that the usual mesh (all rows cast) never loads the flags, and a mesh that casts no
+    // shadow at all is not walked (its walk is still counted when COUNT asks for the
+    // reference's work)
+    const bool flagged = SHADOW && T.shadow_casters != RTAMD_CASTERS_ALL;
+    if (SHADOW && !COUNT && T.shadow_casters == RTAMD_CASTERS_NONE) return;
     double t_near = 0, t_far = 0, t_exit = 0;
     bool walking = active && root_box(T, r, t_near, t_exit);
     t_far = t_exit;
@@ -426,16 +466,18 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         if (small) {
             if (SHADOW) {
                 for (int32_t i = 0; i < count; ++i) {
-                    if (S.tri_prim[first + i] & NO_SHADOW_BIT) continue;         // geometry.py:433-434
+                    const TriRow row = load_row(S, first + i);
+                    if (row.prim & NO_SHADOW_BIT) continue;                      // geometry.py:433-434
                     w.tri(1);
                     double a, b, t;
-                    if (tri_solve_ref(geom, first + i, r, a, b, t)) { best.t = t; found = true; break; }
+                    if (tri_solve_v(row.v0, row.e1, row.e2, r, a, b, t)) { best.t = t; found = true; break; }
                 }
             } else {
                 w.tri((uint32_t)count);
                 for (int32_t i = 0; i < count; ++i) {
+                    const TriRow row = load_row(S, first + i);
                     double a, b, t;
-                    if (tri_solve_ref(geom, first + i, r, a, b, t) && (!found || best.t > t)) {
+                    if (tri_solve_v(row.v0, row.e1, row.e2, r, a, b, t) && (!found || best.t > t)) {
                         best.t = t; best.alpha = a; best.beta = b; best.ref = first + i; found = true;
                     }
                 }
@@ -447,12 +489,56 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         const bool pack16 = walking && !small && count <= 16;
         const bool pack32 = walking && !small && !pack16 && count <= 32;
         const unsigned long long p16 = __ballot(pack16), p32 = __ballot(pack32);
-        if (p16) packed_leaves<COUNT, SHADOW, 16>(S, p16, r, first, count, w, found, best);
+        if (p16) packed_leaves<COUNT, SHADOW, 16>(S, flagged, p16, r, first, count, w, found, best);
         clk.lap(PH_PACK16);
-        if (p32) packed_leaves<COUNT, SHADOW, 32>(S, p32, r, first, count, w, found, best);
+        if (p32) packed_leaves<COUNT, SHADOW, 32>(S, flagged, p32, r, first, count, w, found, best);
         clk.lap(PH_PACK32);
 
         unsigned long long big = __ballot(walking && !small && count > 32);
+#ifndef RT_NO_LANE_BOXED
+        if (!SHADOW && S.leaf_boxes) {
+            // closest-hit queries on boxed leaves: each lane scans its own leaf
+            const bool mine = walking && !small && count > 32 && cbase >= 0;
+            const unsigned long long pm = __ballot(mine);
+            if (pm) {
+                if (mine) {
+                    boxed_leaf_closest_lane(S, r, first, count, cbase, found, best);
+                    w.tri((uint32_t)count);
+                }
+                big &= ~pm;
+                clk.lap(PH_BIG_BOXES);
+            }
+        }
+#endif
+        // Shadow queries on boxed leaves, first part: every lane tests its own ray against
+        // the chunk boxes of its own leaf (lanes of a wave mostly share a few big leaves, so
+        // these loads coalesce), leaving a mask of touched chunks.  The rays are then taken
+        // one at a time below, with no box step of their own.
+        unsigned long long my_chunks = 0;
+        bool my_any_hit_decides = true;
+#ifndef RT_NO_BOX_PREPASS
+        const bool prepass = SHADOW && S.leaf_boxes != nullptr;
+        if (prepass && walking && !small && cbase >= 0 && count <= 4096) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const double ix = 1.0 / r.d.x, iy = 1.0 / r.d.y, iz = 1.0 / r.d.z;
+            const int32_t nch = (count + 63) >> 6;
+            for (int32_t j = 0; j < nch; ++j) {
+                const d2* p = reinterpret_cast<const d2*>(S.leaf_boxes + (int64_t)(cbase + j) * 54);
+                const d2 a = p[0], b = p[1], c = p[2];
+                const double x0 = (a.x - r.o.x) * ix, x1 = (b.y - r.o.x) * ix;
+                const double y0 = (a.y - r.o.y) * iy, y1 = (c.x - r.o.y) * iy;
+                const double z0 = (b.x - r.o.z) * iz, z1 = (c.y - r.o.z) * iz;
+                const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+                const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+                if (!(tn > tf) && !(tf < 0.0)) {
+                    my_chunks |= 1ull << j;
+                    if (!(tf < limit)) my_any_hit_decides = false;
+                }
+            }
+        }
+#else
+        const bool prepass = false;
+#endif
         while (big) {
             const int src = first_lane(big);
             big &= big - 1;
@@ -477,7 +563,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 const bool in = i < qcount;
                 const int32_t ref = qfirst + i;
                 bool usable = in;
-                if (SHADOW) usable = in && !(S.tri_prim[in ? ref : qfirst] & NO_SHADOW_BIT);   // geometry.py:433-434
+                if (SHADOW && flagged) usable = in && !(S.tri_prim[in ? ref : qfirst] & NO_SHADOW_BIT);   // geometry.py:433-434
                 double a, b, t;
                 if (usable && tri_solve_ref(geom, ref, q, a, b, t)) {
                     const int32_t ord = S.tri_order ? S.tri_order[ref] : ref;
@@ -493,63 +579,52 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 }
             };
 
-            if (qbox >= 0) {
+            if (qbox >= 0 && prepass && qcount <= 4096) {
+                // chunks named by the lane's own box tests above; when every touched box ends
+                // before `limit` any hit decides the query (see below) and the first chunk
+                // with a hit ends it
+                const uint32_t lo = (uint32_t)bcast_i((int)(uint32_t)my_chunks, src);
+                const uint32_t hi = (uint32_t)bcast_i((int)(uint32_t)(my_chunks >> 32), src);
+                unsigned long long todo = ((unsigned long long)hi << 32) | lo;
+                const bool any_hit_decides = !COUNT && bcast_i((int)my_any_hit_decides, src) != 0;
+                while (todo) {
+                    const int32_t c = (int32_t)__builtin_ctzll(todo) << 6;
+                    todo &= todo - 1;
+                    test_chunk(c);
+                    if (any_hit_decides && __ballot(lfound)) break;
+                }
+            } else if (qbox >= 0) {
                 // leaf with chunk boxes: lane j tests the box of chunk j against the ray's line,
-                // then the wave visits only chunks that can still matter:
-                //  * closest hit: nearest box first; a chunk whose box the ray enters beyond
-                //    the best t so far cannot hold a closer (or equal) hit and is dropped;
-                //  * shadow: when every touched box ends before `limit` (always, without a
-                //    limit) any hit decides the query the same way as the first one in scan
-                //    order would (light.py:34-35, :127-128), so the first chunk with a hit
-                //    ends it; otherwise all touched chunks are scanned for the earliest item.
+                // then the wave visits the touched chunks.  Shadow queries: when every touched
+                // box ends before `limit` (always, without a limit) any hit decides the query
+                // the same way as the first one in scan order would (light.py:34-35,
+                // :127-128), so the first chunk with a hit ends it; otherwise all touched
+                // chunks are scanned for the earliest item.
                 const double ix = 1.0 / q.d.x, iy = 1.0 / q.d.y, iz = 1.0 / q.d.z;
                 const double* __restrict__ cb = S.chunk_boxes;
                 const int64_t nc = S.n_chunks;
                 const double qlimit = SHADOW ? bcast_d(limit, src) : 0.0;
-                uint32_t bound = 0x7f800000u;          // float bits of an upper bound of the best t (closest)
                 for (int32_t c0 = 0; c0 < n_chunks && !stop; c0 += 64) {
                     const int32_t j = c0 + lane;
                     bool touch = false;
-                    double tn = 0, tf = 0;
+                    double tf = 0;
                     if (j < n_chunks) {
                         const double* bx = cb + qbox + j;
                         const double x0 = (bx[0] - q.o.x) * ix, x1 = (bx[3 * nc] - q.o.x) * ix;
                         const double y0 = (bx[nc] - q.o.y) * iy, y1 = (bx[4 * nc] - q.o.y) * iy;
                         const double z0 = (bx[2 * nc] - q.o.z) * iz, z1 = (bx[5 * nc] - q.o.z) * iz;
                         // fmin/fmax drop NaNs (0*inf on a slab boundary), which keeps the test conservative
-                        tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+                        const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
                         tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
                         touch = !(tn > tf) && !(tf < 0.0);
                     }
-                    if (!SHADOW) {
-                        // key = float lower bound of the entry distance (6 low bits give way to
-                        // the lane number), so the wave minimum names the nearest chunk
-                        uint32_t key = 0xFFFFFFFFu;
-                        if (touch) key = (float_bits_below(tn) & ~63u) | (uint32_t)lane;
-                        for (;;) {
-                            if (key != 0xFFFFFFFFu && (key & ~63u) > bound) key = 0xFFFFFFFFu;
-                            const uint32_t kmin = wave_min_u32(key);
-                            if (kmin == 0xFFFFFFFFu) break;
-                            const int jl = (int)(kmin & 63u);
-                            if (lane == jl) key = 0xFFFFFFFFu;
-                            const bool before = lfound;
-                            const double t_before = lt;
-                            test_chunk((c0 + jl) << 6);
-                            const bool improved = lfound && (!before || lt < t_before);
-                            if (__ballot(improved)) {
-                                const uint32_t up = lfound ? float_bits_above(lt) : 0x7f800000u;
-                                bound = wave_min_u32(up);
-                            }
-                        }
-                    } else {
-                        unsigned long long todo = __ballot(touch);
-                        const bool any_hit_decides = !COUNT && n_chunks <= 64 && !__ballot(touch && !(tf < qlimit));
-                        while (todo) {
-                            const int32_t c = (c0 + first_lane(todo)) << 6;
-                            todo &= todo - 1;
-                            test_chunk(c);
-                            if (any_hit_decides && __ballot(lfound)) { stop = true; break; }
-                        }
+                    unsigned long long todo = __ballot(touch);
+                    const bool any_hit_decides = SHADOW && !COUNT && n_chunks <= 64 && !__ballot(touch && !(tf < qlimit));
+                    while (todo) {
+                        const int32_t c = (c0 + first_lane(todo)) << 6;
+                        todo &= todo - 1;
+                        test_chunk(c);
+                        if (any_hit_decides && __ballot(lfound)) { stop = true; break; }
                     }
                 }
             } else {

@@ -26,7 +26,12 @@ import numpy
 from . import capi
 
 CHUNK = 64
+CELL = 8
 PAD = 1.0e-9
+
+
+def _padded(lo, hi):
+    return lo - PAD * (1.0 + numpy.abs(lo)), hi + PAD * (1.0 + numpy.abs(hi))
 
 
 def _morton_order(centroids):
@@ -50,6 +55,7 @@ def device_arrays(flat):
     order = numpy.arange(n_refs, dtype=numpy.int32)
     nodes = a["kd_nodes"].view([("split", "<f8"), ("a", "<i4"), ("b", "<i4")]).copy()
     boxes_lo, boxes_hi = [], []
+    leaf_boxes = []                     # per chunk: [9][6] = chunk box, then its eight cell boxes
     n_chunks = 0
     leaves = numpy.nonzero((nodes["b"] & 3) == 3)[0]
     counts = nodes["b"][leaves] >> 2
@@ -68,8 +74,15 @@ def device_arrays(flat):
         nodes["split"][node] = float(n_chunks)
         for c in range(0, int(count), CHUNK):
             blo, bhi = lo[c:c + CHUNK].min(axis=0), hi[c:c + CHUNK].max(axis=0)
-            boxes_lo.append(blo - PAD * (1.0 + numpy.abs(blo)))
-            boxes_hi.append(bhi + PAD * (1.0 + numpy.abs(bhi)))
+            blo, bhi = _padded(blo, bhi)
+            boxes_lo.append(blo)
+            boxes_hi.append(bhi)
+            rec = numpy.zeros((1 + CHUNK // CELL, 6))
+            rec[0, 0:3], rec[0, 3:6] = blo, bhi
+            for k in range(0, min(CHUNK, int(count) - c), CELL):
+                klo, khi = _padded(lo[c + k:c + k + CELL].min(axis=0), hi[c + k:c + k + CELL].max(axis=0))
+                rec[1 + k // CELL, 0:3], rec[1 + k // CELL, 3:6] = klo, khi
+            leaf_boxes.append(rec)
             n_chunks += 1
     if n_chunks:
         chunk_boxes = numpy.ascontiguousarray(numpy.concatenate([numpy.array(boxes_lo).T, numpy.array(boxes_hi).T], axis=0))
@@ -78,6 +91,11 @@ def device_arrays(flat):
     a["tri_geom"] = numpy.ascontiguousarray(geom).ravel()
     a["tri_prim"] = prim
     a["tri_order"] = order
+    rows = numpy.zeros((n_refs, 10))
+    rows[:, :9] = geom.T
+    rows[:, 9] = numpy.stack([prim.astype(numpy.int32), order], axis=1).copy().view(numpy.float64)[:, 0]
+    a["tri_rows"] = rows.ravel()
     a["chunk_boxes"] = chunk_boxes.ravel()
+    a["leaf_boxes"] = numpy.concatenate(leaf_boxes).ravel() if leaf_boxes else numpy.zeros(0)
     a["kd_nodes"] = nodes.view(numpy.uint8)
     return a, n_chunks

@@ -182,6 +182,8 @@ class _Flattener(object):
             if key not in mat_cache:
                 mat_cache[key] = self.material_id(tri.material)
             mats[i] = mat_cache[key]
+        t.shadow_casters = (capi.CASTERS_ALL if not flags.any() else
+                            capi.CASTERS_NONE if flags.all() else capi.CASTERS_MIXED)
         self.prim_normals.append(normals.ravel())
         self.prim_normal_offset.append(self.n_normal_doubles + width * numpy.arange(n_prims, dtype=numpy.int64))
         self.prim_material.append(mats)

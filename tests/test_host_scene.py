@@ -117,6 +117,11 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
     assert numpy.array_equal(dev["tri_prim"], flat.arrays["tri_prim"][order])
     nodes = dev["kd_nodes"].view([("split", "<f8"), ("a", "<i4"), ("b", "<i4")])
     boxes = dev["chunk_boxes"].reshape(6, n_chunks)
+    leaf_boxes = dev["leaf_boxes"].reshape(n_chunks, 9, 6)
+    rows_aos = dev["tri_rows"].reshape(n, 10)
+    assert numpy.array_equal(rows_aos[:, :9], geom.T)
+    meta = numpy.ascontiguousarray(rows_aos[:, 9]).view(numpy.int32).reshape(n, 2)
+    assert numpy.array_equal(meta[:, 0], dev["tri_prim"]) and numpy.array_equal(meta[:, 1], order)
     seen = 0
     for nd in nodes[(nodes["b"] & 3) == 3]:
         first, count = int(nd["a"]), int(nd["b"]) >> 2
@@ -131,6 +136,13 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
             pts = numpy.concatenate([g[0:3], g[0:3] + g[3:6], g[0:3] + g[6:9]], axis=1)
             b = boxes[:, base + c // device_layout.CHUNK]
             assert (pts.min(axis=1) > b[0:3]).all() and (pts.max(axis=1) < b[3:6]).all()
+            rec = leaf_boxes[base + c // device_layout.CHUNK]
+            assert numpy.array_equal(rec[0], b)
+            for k in range(0, g.shape[1], device_layout.CELL):
+                cell = g[:, k:k + device_layout.CELL]
+                cp = numpy.concatenate([cell[0:3], cell[0:3] + cell[3:6], cell[0:3] + cell[6:9]], axis=1)
+                kb = rec[1 + k // device_layout.CELL]
+                assert (cp.min(axis=1) > kb[0:3]).all() and (cp.max(axis=1) < kb[3:6]).all()
             seen += 1
     assert seen == n_chunks and n_chunks > 0
 
