@@ -409,13 +409,15 @@ __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& 
 // leaf order that reports a hit ends the query and its t is returned.
 template <bool COUNT, bool SHADOW>
 __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool active, const Ray& r,
-                              double limit, const KdStack& stk, Work<COUNT>& w, bool& found, TriHit& best) {
+                              double limit, bool coherent, const KdStack& stk, Work<COUNT>& w, bool& found,
+                              TriHit& best) {
     found = false;
     // rows carry a does-not-cast-shadows bit; the tree says whether any row has it, so
     // that the usual mesh (all rows cast) never loads the flags, and a mesh that casts no
     // shadow at all is not walked (its walk is still counted when COUNT asks for the
     // reference's work)
     const bool flagged = SHADOW && T.shadow_casters != RTAMD_CASTERS_ALL;
+    const bool lane_scans = !SHADOW && coherent && S.leaf_boxes != nullptr;
     if (SHADOW && !COUNT && T.shadow_casters == RTAMD_CASTERS_NONE) return;
     double t_near = 0, t_far = 0, t_exit = 0;
     bool walking = active && root_box(T, r, t_near, t_exit);
@@ -462,7 +464,10 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         }
 
         clk.lap(PH_DESCENT);
-        const bool small = walking && count <= SMALL_LEAF;
+        // rays of one tile that have not bounced yet run close together: their lanes reach
+        // the same leaves and read the same rows, so each lane scans its own leaf; rays
+        // that have scattered are tested by the wave together (packed and chunk steps below)
+        const bool small = walking && (lane_scans ? cbase < 0 : count <= SMALL_LEAF);
         if (small) {
             if (SHADOW) {
                 for (int32_t i = 0; i < count; ++i) {
@@ -496,8 +501,8 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
 
         unsigned long long big = __ballot(walking && !small && count > 32);
 #ifndef RT_NO_LANE_BOXED
-        if (!SHADOW && S.leaf_boxes) {
-            // closest-hit queries on boxed leaves: each lane scans its own leaf
+        if (lane_scans) {
+            // boxed leaves as well: each lane scans its own leaf through the cell boxes
             const bool mine = walking && !small && count > 32 && cbase >= 0;
             const unsigned long long pm = __ballot(mine);
             if (pm) {
@@ -797,8 +802,8 @@ struct Hit {
 };
 
 // World.hit_objects (main.py:35-46) for every active lane: objects in list order, strict `<`.
-template <bool COUNT>
-__device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, bool active, const Ray& ray,
+template <bool COUNT, bool TREES>
+__device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, bool active, bool coherent, const Ray& ray,
                                  Work<COUNT>& w, Hit& h) {
     if (active) w.closest++;
     double tmin = T_INF;
@@ -811,12 +816,12 @@ __device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, 
         V3 n = v3(0, 0, 0);
         int32_t mat = ob.material, prim = -1;
         bool hit = false;
-        if (ob.kind == RTAMD_KDTREE) {
+        if (TREES && ob.kind == RTAMD_KDTREE) {
             if (__ballot(active)) {
                 const rtamd_tree& T = S.trees[ob.tree];
                 TriHit th;
                 bool f;
-                kd_query_wave<COUNT, false>(S, T, active, r, 0.0, stk, w, f, th);
+                kd_query_wave<COUNT, false>(S, T, active, r, 0.0, coherent, stk, w, f, th);
                 if (active && f) {
                     hit = true;
                     t = th.t;
@@ -883,7 +888,7 @@ __device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, 
 
 // light.in_shadow for every lane with `need`: any object that reports a hit [closer than
 // `limit`] (light.py:31-37 / :124-130 with a distance, :60-65 / :78-83 / :170-175 without).
-template <bool COUNT>
+template <bool COUNT, bool TREES>
 __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, bool need, const Ray& ray,
                               bool use_limit, double limit, Work<COUNT>& w) {
     if (need) w.shadow++;
@@ -895,11 +900,11 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
         const double* p = ob.p;
         double t = 0;
         bool hit = false;
-        if (ob.kind == RTAMD_KDTREE) {
+        if (TREES && ob.kind == RTAMD_KDTREE) {
             if (__ballot(q)) {
                 TriHit th;
                 bool f;
-                kd_query_wave<COUNT, true>(S, S.trees[ob.tree], q, r, use_limit ? limit : T_INF * 4.0, stk, w, f, th);
+                kd_query_wave<COUNT, true>(S, S.trees[ob.tree], q, r, use_limit ? limit : T_INF * 4.0, false, stk, w, f, th);
                 hit = q && f;
                 t = th.t;
             }
@@ -978,7 +983,7 @@ __device__ __forceinline__ V3 texture_color(const rtamd_scene_desc& S, int tex, 
 // visited in list order by the whole wave so that the shadow queries stay wave-wide.
 // EXT: `tex` is the texture colour of an SV_Matte hit (material.py:311-326), which scales
 // ka and kd and adds the viewer-side test of :319.
-template <bool COUNT, bool EXT>
+template <bool COUNT, bool EXT, bool TREES>
 __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, bool lit, const rtamd_material& m,
                                 const Hit& h, V3 wo, bool area, V3 tex, Draw& dr, Work<COUNT>& w) {
     // ambient_color.L(sr): AmbientLight (light.py:14-15) or AmbientOccluder (light.py:85-100)
@@ -988,7 +993,7 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
         sr.o = h.p;
         sr.d = v3(0, 0, 1);
         if (lit) sr.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
-        if (occluded_wave<COUNT>(S, stk, lit, sr, false, 0.0, w)) amb = ld3(S.ambient.occluded);
+        if (occluded_wave<COUNT, TREES>(S, stk, lit, sr, false, 0.0, w)) amb = ld3(S.ambient.occluded);
     }
     const bool textured = EXT && m.kind == RTAMD_SV_MATTE;
     V3 L = (textured ? ld3(m.ambient) * tex : ld3(m.ambient)) * amb;
@@ -1030,7 +1035,7 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
             if (lt.kind == RTAMD_POINT) limit = norm(sr.o - ld3(lt.position));                    // light.py:32
             else if (lt.kind == RTAMD_AREA) limit = dot(sample_point - sr.o, sr.d);               // light.py:125
             const bool bounded = lt.kind == RTAMD_POINT || lt.kind == RTAMD_AREA;
-            if (__ballot(facing)) in_shadow = occluded_wave<COUNT>(S, stk, facing, sr, bounded, limit, w);
+            if (__ballot(facing)) in_shadow = occluded_wave<COUNT, TREES>(S, stk, facing, sr, bounded, limit, w);
         }
         if (!facing || in_shadow || !gate) continue;
         V3 f = ld3(m.diffuse);
@@ -1094,7 +1099,7 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(pow(b.x, e), pow(
 // depth first in the reference's order - reflected subtree, then the refracted one - with
 // the waiting siblings in a per-lane list (one per level, RTAMD_MAX_BRANCH_LEVELS), so the
 // in-trace draw counter advances exactly as in the recursive formulation.
-template <bool COUNT, bool EXT>
+template <bool COUNT, bool EXT, bool TREES>
 __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, Primary& first) {
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
@@ -1124,7 +1129,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
         }
         Hit h;
         h.p = v3(0, 0, 0); h.n = v3(0, 0, 1); h.material = 0;
-        const bool hit = closest_hit_wave<COUNT>(S, stk, alive, ray, w, h);
+        const bool hit = closest_hit_wave<COUNT, TREES>(S, stk, alive, primary, ray, w, h);
         if (alive && !hit) { L = L + W * background; alive = false; }
         if (alive && primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; }
         primary = false;
@@ -1162,7 +1167,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
         V3 tex = v3(1, 1, 1);
         if (EXT && alive && m.kind == RTAMD_SV_MATTE)
             tex = texture_color(S, m.texture, local_hit_point(S.objects[h.object], ray, h.t));
-        const V3 Ld = direct_light_wave<COUNT, EXT>(S, stk, alive, m, h, wo, area, tex, dr, w);
+        const V3 Ld = direct_light_wave<COUNT, EXT, TREES>(S, stk, alive, m, h, wo, area, tex, dr, w);
         if (alive) L = L + W * Ld;
         if (area) { alive = false; continue; }
         if (!alive) continue;

@@ -74,7 +74,9 @@ __device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point,
 // textured ones (SV_Matte); they keep a per-lane list of waiting child rays in private
 // memory and a texture colour across the shadow queries, which the other instantiations
 // do not pay for.
-template <int MODE, bool COUNT, bool EXT>
+// TREES = false instantiations serve scenes without a kd-tree (analytic primitives only):
+// no traversal code, no LDS stack, and the registers go to the shading loop.
+template <int MODE, bool COUNT, bool EXT, bool TREES>
 __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
     // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
@@ -153,12 +155,12 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         dr.counter = 0;
         Primary first;
         // the wave's kd traversal stack (one wave per workgroup)
-        __shared__ double stack_t[LDS_STACK * 64];
-        __shared__ int32_t stack_node[LDS_STACK * 64];
+        __shared__ double stack_t[TREES ? LDS_STACK * 64 : 1];
+        __shared__ int32_t stack_node[TREES ? LDS_STACK * 64 : 1];
         KdStack stk;
         stk.node = stack_node;
         stk.t = stack_t;
-        const V3 c = trace_wave<COUNT, EXT>(S, stk, live, ray, A.depth0, dr, work, first);
+        const V3 c = trace_wave<COUNT, EXT, TREES>(S, stk, live, ray, A.depth0, dr, work, first);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
             if (A.out.rgb) { A.out.rgb[3 * k] = c.x; A.out.rgb[3 * k + 1] = c.y; A.out.rgb[3 * k + 2] = c.z; }
@@ -221,6 +223,7 @@ int hip_fail(hipError_t e, const char* what) {
 
 template <int MODE>
 int launch(const rtamd_scene_desc& S, bool extended, LaunchArgs& A, uint32_t flags, void* stream) {
+    const bool trees = S.n_trees > 0;
     if (A.n <= 0) return RTAMD_OK;
     A.seg_len = 0;
 #if RT_XCD_SEGMENTS > 0
@@ -236,11 +239,14 @@ int launch(const rtamd_scene_desc& S, bool extended, LaunchArgs& A, uint32_t fla
     const bool count = (flags & RTAMD_COUNT_WORK) != 0;
     const dim3 grid((unsigned)blocks), block(BLOCK);
     if (extended) {
-        if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, true>), grid, block, 0, st, S, A);
-        else hipLaunchKernelGGL((trace_kernel<MODE, false, true>), grid, block, 0, st, S, A);
+        if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, true, true>), grid, block, 0, st, S, A);
+        else hipLaunchKernelGGL((trace_kernel<MODE, false, true, true>), grid, block, 0, st, S, A);
+    } else if (trees) {
+        if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false, true>), grid, block, 0, st, S, A);
+        else hipLaunchKernelGGL((trace_kernel<MODE, false, false, true>), grid, block, 0, st, S, A);
     } else {
-        if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false>), grid, block, 0, st, S, A);
-        else hipLaunchKernelGGL((trace_kernel<MODE, false, false>), grid, block, 0, st, S, A);
+        if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false, false>), grid, block, 0, st, S, A);
+        else hipLaunchKernelGGL((trace_kernel<MODE, false, false, false>), grid, block, 0, st, S, A);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
