@@ -255,6 +255,9 @@ typedef struct rtamd_scene_desc {
     const double *sampler_data;         /* device */
     const rtamd_tree *trees;            /* device */
     const rtamd_kdnode *kd_nodes;       /* device */
+    const rtamd_kdnode *kd_triples;     /* device: [n_kd_nodes][4] = node i, its left child, its right
+                                           child (zeros for a leaf), one unused record: what a
+                                           traversal step reads, two tree levels per 64-byte load */
     const double *tri_geom;             /* device */
     const int32_t *tri_prim;            /* device */
     const int32_t *tri_order;           /* device, optional */

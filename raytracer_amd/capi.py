@@ -77,7 +77,7 @@ class SceneDesc(C.Structure):
                 ("background", d3), ("ambient", Ambient),
                 ("objects", C.c_void_p), ("materials", C.c_void_p), ("lights", C.c_void_p),
                 ("samplers", C.c_void_p), ("sampler_data", C.c_void_p), ("trees", C.c_void_p),
-                ("kd_nodes", C.c_void_p), ("tri_geom", C.c_void_p), ("tri_prim", C.c_void_p),
+                ("kd_nodes", C.c_void_p), ("kd_triples", C.c_void_p), ("tri_geom", C.c_void_p), ("tri_prim", C.c_void_p),
                 ("tri_order", C.c_void_p), ("tri_rows", C.c_void_p), ("leaf_boxes", C.c_void_p), ("chunk_boxes", C.c_void_p),
                 ("prim_normals", C.c_void_p), ("prim_normal_offset", C.c_void_p),
                 ("prim_material", C.c_void_p),

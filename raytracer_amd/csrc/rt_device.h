@@ -435,8 +435,10 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     while (__ballot(walking)) {
         int32_t first = 0, count = 0, cbase = -1;
         if (walking) {
-            rtamd_kdnode nd = S.kd_nodes[node];
-            while ((nd.b & 3) != 3) {
+            // One interior step of KDTree.iterate_nodes (kdtree.py:140-153) at `node`, whose
+            // record is nd: picks the next node and pushes the far child where the ray
+            // crosses the split plane inside (t_near, t_far).
+            auto step = [&](const rtamd_kdnode& nd) {
                 w.node();
                 const int ax = nd.b;
                 const double o = axis_of(r.o, ax), d = axis_of(r.d, ax);
@@ -455,7 +457,18 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                     node = near_n;
                     t_far = t;
                 }
-                nd = S.kd_nodes[node];
+            };
+            // a 64-byte record holds a node and both its children, so every load serves two levels
+            const rtamd_kdnode* rec = S.kd_triples + (int64_t)node * 4;
+            rtamd_kdnode nd = rec[0], left = rec[1], right = rec[2];
+            while ((nd.b & 3) != 3) {
+                const int32_t left_index = node + 1;
+                step(nd);
+                nd = node == left_index ? left : right;
+                if ((nd.b & 3) == 3) break;
+                step(nd);
+                rec = S.kd_triples + (int64_t)node * 4;
+                nd = rec[0]; left = rec[1]; right = rec[2];
             }
             w.leaf();
             first = nd.a;

@@ -303,7 +303,7 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
     if ((d->n_objects && !d->objects) || (d->n_materials && !d->materials) || (d->n_lights && !d->lights) ||
         !d->samplers || !d->sampler_data)
         return fail(RTAMD_EINVAL, "a non-empty table has a null pointer%s");
-    if (d->n_trees && (!d->trees || !d->kd_nodes || !d->tri_geom || !d->tri_prim || !d->prim_normals ||
+    if (d->n_trees && (!d->trees || !d->kd_nodes || !d->kd_triples || !d->tri_geom || !d->tri_prim || !d->prim_normals ||
                        !d->prim_normal_offset || !d->prim_material))
         return fail(RTAMD_EINVAL, "kd-tree tables missing%s");
     if (d->leaf_boxes && (!d->tri_rows || !d->chunk_boxes || !d->tri_order))

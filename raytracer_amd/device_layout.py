@@ -98,4 +98,11 @@ def device_arrays(flat):
     a["chunk_boxes"] = chunk_boxes.ravel()
     a["leaf_boxes"] = numpy.concatenate(leaf_boxes).ravel() if leaf_boxes else numpy.zeros(0)
     a["kd_nodes"] = nodes.view(numpy.uint8)
+    # node, left child, right child side by side: two levels of the walk per load
+    triples = numpy.zeros((len(nodes), 4), dtype=nodes.dtype)
+    triples[:, 0] = nodes
+    interior = numpy.nonzero((nodes["b"] & 3) != 3)[0]
+    triples[interior, 1] = nodes[interior + 1]
+    triples[interior, 2] = nodes[nodes["a"][interior]]
+    a["kd_triples"] = triples.view(numpy.uint8).ravel()
     return a, n_chunks

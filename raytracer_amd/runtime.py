@@ -52,6 +52,7 @@ class DeviceScene(object):
             desc = self.flat.desc(lambda name, arr: self.tensors[name].data_ptr())
             desc.tri_order = self.tensors["tri_order"].data_ptr()
             desc.tri_rows = self.tensors["tri_rows"].data_ptr()
+            desc.kd_triples = self.tensors["kd_triples"].data_ptr()
             desc.leaf_boxes = self.tensors["leaf_boxes"].data_ptr()
             desc.chunk_boxes = self.tensors["chunk_boxes"].data_ptr()
             desc.n_chunks = n_chunks

@@ -33,7 +33,8 @@ for d in sorted(glob.glob(out + "/*/")):
             k = r["Kernel_Name"]
             if "trace_kernel" not in k:
                 continue
-            key = "counting" if ", true>" in k else "timed"
+            args = k[k.index("<") + 1:k.rindex(">")].replace(" ", "").split(",")    # MODE, COUNT, EXT, TREES
+            key = "counting" if len(args) > 1 and args[1] in ("true", "1") else "timed"
             e = res.setdefault(key, {"dispatches": {}})
             e["vgpr"], e["sgpr"], e["scratch"], e["grid"], e["wg"] = r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["Grid_Size"], r["Workgroup_Size"]
             e.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
