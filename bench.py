@@ -108,14 +108,25 @@ def main():
     ds.read_counters(reset=True)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # two accumulators in flight: the gather of frame i runs on RCCL's stream while the
+    # kernel of frame i+1 renders into the other buffer
+    bufs, recv = job.pipeline(2)
+    pending = [None, None]
     t0 = time.perf_counter()
     for i in range(args.steps):
+        k = i % 2
+        if pending[k] is not None:
+            pending[k].wait()               # the buffer's previous gather has read it
+        bufs[k].zero_()
         # events bracket the tile kernel on the stream it is launched on (torch's current stream)
-        job.sum_rgb8.zero_()
         ev0[i].record()
-        job.render_fn(job.tile_ids, job.sum_rgb8, None)
+        job.render_fn(job.tile_ids, bufs[k], None)
         ev1[i].record()
-        parts = distributed.gather_to_root(job.sum_rgb8)
+        pending[k] = distributed.gather_to_root(bufs[k], parts=recv[k], async_op=True)
+    parts = None
+    for k in ((args.steps - 2) % 2, (args.steps - 1) % 2) if args.steps > 1 else (0,):
+        if pending[k] is not None:
+            parts = pending[k].wait()       # the last frame's gather is waited for last
     barrier()
     elapsed = time.perf_counter() - t0
     counters = ds.read_counters(reset=True)

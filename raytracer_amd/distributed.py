@@ -32,26 +32,49 @@ def padded_tile_count(width, height, world_size):
     return int(numpy.bincount(owners, minlength=world_size).max())
 
 
-def gather_to_root(local, dist=None, root=0):
-    """Gather equal-shaped per-rank tensors on `root`; returns the list there, None elsewhere."""
+class PendingGather(object):
+    """A gather that may still be running on the collective's own stream."""
+
+    def __init__(self, parts, work=None):
+        self.parts, self.work = parts, work
+
+    def wait(self):
+        """Order the caller's stream after the gather; returns the root's list (None elsewhere)."""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.parts
+
+
+def gather_to_root(local, dist=None, root=0, parts=None, async_op=False):
+    """Gather equal-shaped per-rank tensors on `root`; returns the list there, None elsewhere.
+
+    `parts` lets the root reuse its receive buffers.  With async_op the collective is only
+    enqueued (RCCL runs it on its own stream once the producing kernel is done, so the
+    next frame's kernel overlaps it) and a PendingGather is returned."""
     import torch
     if dist is None:
         import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return [local]
+        return PendingGather([local]) if async_op else [local]
     world = dist.get_world_size()
     rank = dist.get_rank()
     if local.is_cuda and dist.get_backend() == "gloo":
         local = local.cpu()             # gloo gathers host tensors (CPU tests, single-GPU rehearsals)
-    parts = [torch.empty_like(local) for _ in range(world)] if rank == root else None
+        parts = None
+    if rank == root and parts is None:
+        parts = [torch.empty_like(local) for _ in range(world)]
+    if rank != root:
+        parts = None
+    work = None
     try:
-        dist.gather(local, gather_list=parts, dst=root)
+        work = dist.gather(local, gather_list=parts, dst=root, async_op=async_op)
     except (RuntimeError, NotImplementedError):
         # a backend without gather: all ranks collect, only the root keeps the result
         every = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(every, local)
+        work = dist.all_gather(every, local, async_op=async_op)
         parts = every if rank == root else None
-    return parts
+    return PendingGather(parts, work) if async_op else parts
 
 
 def assemble(parts, width, height, world_size):
@@ -100,6 +123,15 @@ class FrameJob(object):
         if len(self.tiles):
             self.render_fn(self.tile_ids, self.sum_rgb8 if want_int else None, None if want_int else self.sum_sq)
         return gather_to_root(acc)
+
+    def pipeline(self, depth=2):
+        """`depth` integer accumulators with their receive lists for frames in flight:
+        frame i renders into buffer i % depth while the gather of frame i-1 still runs."""
+        import torch
+        bufs = [self.sum_rgb8] + [torch.zeros_like(self.sum_rgb8) for _ in range(depth - 1)]
+        is_root = self.rank == 0 and self.world_size > 1
+        recv = [[torch.empty_like(b) for _ in range(self.world_size)] if is_root else None for b in bufs]
+        return bufs, recv
 
     def finish(self, parts):
         """On rank 0: the frame as uint8 (height, width, 3), by the rules of main.py:99-106

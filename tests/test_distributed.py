@@ -49,6 +49,22 @@ def _worker(rank, world_size, port, scene, overrides, out_path):
             numpy.save(out_path + "." + mode + ".npy", frame)
         else:
             assert frame is None
+    # frames in flight, as the benchmark runs them: render into alternating buffers with
+    # the previous frame's gather still pending
+    job = distributed.FrameJob(world, rank, world_size, render_fn=render_fn, mode="parallel")
+    bufs, recv = job.pipeline(2)
+    pending = [None, None]
+    for i in range(3):
+        k = i % 2
+        if pending[k] is not None:
+            pending[k].wait()
+        bufs[k].zero_()
+        job.render_fn(job.tile_ids, bufs[k], None)
+        pending[k] = distributed.gather_to_root(bufs[k], parts=recv[k], async_op=True)
+    pending[1].wait()
+    frame = job.finish(pending[0].wait())
+    if rank == 0:
+        assert numpy.array_equal(frame, numpy.load(out_path + ".parallel.npy"))
     dist.destroy_process_group()
 
 
