@@ -57,6 +57,9 @@ PLAN = {
     "features_pane":    ("parallel", None, 3000),
     "features_texture": ("parallel", None, 5000),
     "glass_teapot":     ("parallel", None, 2500),
+    # RegularSampler everywhere (the scene files' "realtime" branch): no draws at all
+    "glossyreflective@realtime": ("realtime", None, 3000),
+    "mirrorhall@realtime": ("realtime", None, 2000),
 }
 
 
@@ -373,7 +376,7 @@ def main(argv):
                 continue
             viewmode, overrides, count = PLAN[scene]
             t0 = time.time()
-            world = harness.build(scene, viewmode, overrides)
+            world = harness.build(scene.split("@")[0], viewmode, overrides)
             print("%s: built in %.1fs" % (scene, time.time() - t0), flush=True)
             pixels, samples = choose_samples(world, count, seed=1234)
             rec = harness.trace_samples(world, pixels, samples)

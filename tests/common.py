@@ -10,7 +10,8 @@ GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 
 GOLDEN_SCENES = ("foursphere", "glossyreflective", "mirrorhall", "mirrorhall_dof", "cornellbox",
                  "cornellbox_area", "features_analytic", "features_mesh", "features_env", "features_glass",
-                 "features_pane", "features_texture", "glass_teapot", "j", "dragon_area")
+                 "features_pane", "features_texture", "glass_teapot", "j", "dragon_area",
+                 "glossyreflective@realtime", "mirrorhall@realtime")
 
 # float comparison bound for radiance: the tolerance of the task statement is 1e-4
 # relative per channel (fp32 device vs Python float64); this build computes in double, so
@@ -34,7 +35,7 @@ def world_for(name):
     world = World.__new__(World)
     if overrides:
         world.overrides = overrides
-    World.__init__(world, viewmode=str(g["viewmode"]), buildfunction=name, seed=int(g["seed"]))
+    World.__init__(world, viewmode=str(g["viewmode"]), buildfunction=name.split("@")[0], seed=int(g["seed"]))
     return world
 
 

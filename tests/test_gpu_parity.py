@@ -40,6 +40,7 @@ def test_gpu_matches_reference_golden(torch_gpu, scene):
     ("features_pane", 40, (1, 4)),
     ("features_texture", 70, (0, 9)),
     ("glass_teapot", 80, (0, 4)),
+    ("glossyreflective@realtime", 64, (0, 1)),
     ("dragon_area", 40, (0, 4)),
     ("dragon_area", 420, (0, 16)),
     ("j", 600, (0, 1)),

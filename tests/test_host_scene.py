@@ -11,13 +11,19 @@ import pytest
 
 from tests import common
 
-TREE_SCENES = ("cornellbox", "cornellbox_area", "features_mesh", "j", "dragon_area")
+TREE_SCENES = ("cornellbox", "cornellbox_area", "features_mesh", "glass_teapot", "j", "dragon_area")
 
 
 @pytest.mark.parametrize("scene", common.GOLDEN_SCENES)
 def test_sampler_tables_match_reference(scene):
     g = common.golden(scene)
     s = common.world_for(scene).viewplane.sampler
+    if "sampler_square" not in g:
+        # a RegularSampler has no tables: one fixed sample, no draws (sampler.py:5-14)
+        assert [tuple(p) for p in s.sample()] == [(0.5, 0.5)]
+        assert numpy.array_equal(s.sample_unit_disk()[0], [0., 0.])
+        assert numpy.array_equal(s.sample_unit_hemisphere_surface(), [0., 0., 1.])
+        return
     assert numpy.array_equal(numpy.array(s.patterns), g["sampler_square"])
     assert numpy.array_equal(numpy.array(s.concentric_patterns), g["sampler_disk"])
     assert numpy.array_equal(numpy.array(s.hemisphere_patterns), g["sampler_hemi"])
