@@ -144,7 +144,15 @@ __device__ __forceinline__ bool tri_solve_v(V3 v0, V3 e1, V3 e2, const Ray& r,
 #endif
     const V3 pvec = cross(r.d, e2);
     const double det = dot(e1, pvec);
+#ifndef RT_EXACT_DIVIDE
+    // reciprocal by two Newton steps on the hardware estimate (within an ulp or so of
+    // 1/det; a zero or denormal det gives inf/NaN and with it a miss, as the division does)
+    double inv = __builtin_amdgcn_rcp(det);
+    inv = fma(inv, fma(-det, inv, 1.0), inv);
+    inv = fma(inv, fma(-det, inv, 1.0), inv);
+#else
     const double inv = 1.0 / det;
+#endif
     const V3 tvec = r.o - v0;
     alpha = dot(tvec, pvec) * inv;
     const V3 qvec = cross(tvec, e1);
