@@ -141,3 +141,38 @@ class SkyAndPanel(BuildFunctionBase):
             Plane(origin=(0, 0, 0), normal=(0, 1, 0), material=Matte(ka=1, kd=1, cd=_rgb(1., 1., 1.))),
         ]
         world.lights = [EnvironmentLight(sky, sampler), AreaLight(glow, panel, 5.)]
+
+
+class Pile(BuildFunctionBase):
+    """4 500 triangles that all span the same box, so the SAH finds nothing to split and the
+    kd-tree is one leaf of several thousand rows (more than 64 chunks of 64): the scan paths
+    for very large leaves, closest hits and shadows alike."""
+    BUILD_FUNCTION_NAME = 'features_pile'
+
+    @classmethod
+    def build_function(cls, world, viewmode):
+        world.viewmode = viewmode
+        sampler = MultiJitteredSampler(sample_dim=1 if viewmode == "realtime" else 2)
+        world.viewplane = ViewPlane(resolution=(64, 48), pixel_size=2.0, sampler=sampler)
+        world.camera = PinholeCamera(eye=(3., 4., 9.), up=(0., 1., 0.), lookat=(0., 1., 0.), viewing_distance=90.)
+        world.background_color = (0.1, 0.1, 0.15)
+        world.tracer = Tracer(world, 2)
+        world.ambient_color = AmbientOccluder(_rgb(1, 1, 1), .5, sampler)
+        straw = Matte(ka=.6, kd=.8, cd=_rgb(.9, .8, .4))
+        r = numpy.random.RandomState(7)
+        boxes = []
+        for i in range(4500):
+            # corner to corner of the unit-ish box, with a random third vertex: every
+            # bounding box is (nearly) the whole pile
+            a = _rgb(-1.5, 0.02, -1.5) + r.uniform(0, 0.05, 3)
+            b = _rgb(1.5, 2.5, 1.5) - r.uniform(0, 0.05, 3)
+            c = _rgb(*r.uniform(-1.5, 1.5, 3)) * _rgb(1, 0, 1) + _rgb(0, r.uniform(0.02, 2.5), 0)
+            tri = Triangle(a, b, c, material=straw)
+            tri.label = str(i)
+            tri.cast_shadow = (i % 7) != 0
+            boxes.extend(tri.get_bounding_boxes())
+        world.objects = [
+            KDTree(BoundingBoxes(boxes)),
+            Plane(origin=(0, 0, 0), normal=(0, 1, 0), material=Matte(ka=.6, kd=.8, cd=_rgb(.8, .8, .8))),
+        ]
+        world.lights = [PointLight(_rgb(1, 1, 1), 2.0, numpy.array((4., 7., 5.)), radius=8, attenuation=2, cast_shadow=True)]
