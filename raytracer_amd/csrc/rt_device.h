@@ -565,6 +565,111 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
 #else
         const bool prepass = false;
 #endif
+#ifndef RT_NO_LEAF_SHARING
+        // Shadow queries, second part: lanes that stand in the same leaf are served together.
+        // For every chunk that any of them touches the wave loads its 64 rows once and tests
+        // them against each of those rays in turn (the ray rides in scalar registers).  A
+        // leaf of 33-64 rows without boxes counts as one chunk.  A ray whose boxes all end
+        // before its limit is decided by any hit (see below); the others keep the hit with
+        // the earliest scan position over all their chunks, as KDTree.shadow_hit reports it.
+        if (SHADOW && !COUNT && prepass) {
+            const bool eligible = walking && !small && count > 32 && (cbase < 0 ? count <= 64 : count <= 4096);
+            if (eligible && cbase < 0) { my_chunks = 1; my_any_hit_decides = false; }
+            const bool has_work = eligible && my_chunks != 0;
+            unsigned long long rest = __ballot(has_work);
+            big &= ~__ballot(eligible);
+            int32_t my_ord = 0x7fffffff;
+            while (rest) {
+                const int s0 = first_lane(rest);
+                const int32_t lf = bcast_i(first, s0), lcount = bcast_i(count, s0);
+                bool open = has_work && first == lf;        // this lane's query is in this leaf and undecided
+                const unsigned long long same = __ballot(open);
+                rest &= ~same;
+                unsigned long long uni = 0;
+                for (unsigned long long m = same; m; m &= m - 1) {
+                    const int s1 = first_lane(m);
+                    const uint32_t lo = (uint32_t)bcast_i((int)(uint32_t)my_chunks, s1);
+                    const uint32_t hi = (uint32_t)bcast_i((int)(uint32_t)(my_chunks >> 32), s1);
+                    uni |= ((unsigned long long)hi << 32) | lo;
+                }
+                while (uni) {
+                    const int32_t cj = (int32_t)__builtin_ctzll(uni);
+                    uni &= uni - 1;
+                    unsigned long long takers = __ballot(open && ((my_chunks >> cj) & 1ull));
+                    if (!takers) continue;
+                    const int32_t i = (cj << 6) + lane;
+                    const bool in = i < lcount;
+                    const int32_t ref = lf + (in ? i : 0);
+                    bool usable = in;
+                    if (flagged) usable = in && !(S.tri_prim[ref] & NO_SHADOW_BIT);               // geometry.py:433-434
+                    const int32_t off = ref * 8;
+                    const V3 v0 = v3(tri_component(geom, off, 0), tri_component(geom, off, 1), tri_component(geom, off, 2));
+                    const V3 e1 = v3(tri_component(geom, off, 3), tri_component(geom, off, 4), tri_component(geom, off, 5));
+                    const V3 e2 = v3(tri_component(geom, off, 6), tri_component(geom, off, 7), tri_component(geom, off, 8));
+                    while (takers) {
+                        const int rl = first_lane(takers);
+                        takers &= takers - 1;
+                        Ray q;
+                        q.o = v3(bcast_d(r.o.x, rl), bcast_d(r.o.y, rl), bcast_d(r.o.z, rl));
+                        q.d = v3(bcast_d(r.d.x, rl), bcast_d(r.d.y, rl), bcast_d(r.d.z, rl));
+                        double a, b, t;
+                        const bool hit = usable && tri_solve_v(v0, e1, e2, q, a, b, t);
+                        const unsigned long long hm = __ballot(hit);
+                        if (!hm) continue;
+                        if (bcast_i((int)my_any_hit_decides, rl) != 0) {
+                            const double ht = bcast_d(t, first_lane(hm));
+                            if (lane == rl) { best.t = ht; found = true; open = false; }
+                        } else {
+                            const int32_t ord = hit ? S.tri_order[ref] : 0x7fffffff;
+                            int wl = first_lane(hm);
+                            for (;;) {
+                                const int32_t ow = bcast_i(ord, wl);
+                                const unsigned long long closer = __ballot(hit && ord < ow);
+                                if (!closer) break;
+                                wl = first_lane(closer);
+                            }
+                            const int32_t ow = bcast_i(ord, wl);
+                            const double ht = bcast_d(t, wl);
+                            if (lane == rl && ow < my_ord) { my_ord = ow; best.t = ht; found = true; }
+                        }
+                    }
+                }
+            }
+            clk.lap(PH_BIG_BOXES);
+        }
+#endif
+#ifdef RT_PHASE_TIMERS
+        if (SHADOW && prepass) {
+            // sharing statistics of boxed leaves: rays, distinct leaves, (ray, chunk) pairs, distinct (leaf, chunk) pairs
+            unsigned long long rest = __ballot(walking && !small && count > 32 && cbase >= 0);
+            unsigned long long n_rays = __popcll(rest), n_leaves = 0, n_pairs = 0, n_distinct = 0;
+            while (rest) {
+                const int s0 = first_lane(rest);
+                const int32_t lf = bcast_i(first, s0);
+                unsigned long long same = __ballot(walking && !small && count > 32 && cbase >= 0 && first == lf);
+                rest &= ~same;
+                n_leaves++;
+                unsigned long long uni = 0;
+                while (same) {
+                    const int s1 = first_lane(same);
+                    same &= same - 1;
+                    const uint32_t lo = (uint32_t)bcast_i((int)(uint32_t)my_chunks, s1);
+                    const uint32_t hi = (uint32_t)bcast_i((int)(uint32_t)(my_chunks >> 32), s1);
+                    const unsigned long long mc = ((unsigned long long)hi << 32) | lo;
+                    n_pairs += __popcll(mc);
+                    uni |= mc;
+                }
+                n_distinct += __popcll(uni);
+            }
+            if (lane == 0 && n_rays) {
+                atomicAdd(&g_phase_cycles[20], n_rays);
+                atomicAdd(&g_phase_cycles[21], n_leaves);
+                atomicAdd(&g_phase_cycles[22], n_pairs);
+                atomicAdd(&g_phase_cycles[23], n_distinct);
+                atomicAdd(&g_phase_cycles[24], 1ull);
+            }
+        }
+#endif
         while (big) {
             const int src = first_lane(big);
             big &= big - 1;

@@ -66,6 +66,9 @@ def main():
             out["%s_%s" % (kind, name)] = t[base + i] / float(total)
         out["%s_queries_per_wave" % kind] = t[base + 6] / float(max(waves, 1))
     out["outside_kd_queries"] = 1.0 - sum(t[0:6] + t[8:14]) / float(total)
+    if t[24]:
+        out["boxed_shadow_sharing"] = {"episodes": t[24], "rays": t[20], "distinct_leaves": t[21],
+                                       "ray_chunk_pairs": t[22], "distinct_leaf_chunk_pairs": t[23]}
     print(json.dumps(out, indent=1))
 
 
