@@ -98,35 +98,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        parts = job.render()
+    # two accumulators in flight: the gather of frame i (int32 per channel on the wire) runs
+    # on RCCL's stream while the kernel of frame i+1 renders into the other buffer
+    bufs, recv = job.pipeline(2)
+
+    def run(steps, ev0=None, ev1=None):
+        pending = [None, None]
+        for i in range(steps):
+            k = i % 2
+            if pending[k] is not None:
+                pending[k].wait()               # the slot's previous gather has read its wire buffer
+            bufs[k].zero_()
+            # events bracket the tile kernel on the stream it is launched on (torch's current stream)
+            if ev0 is not None:
+                ev0[i].record()
+            job.render_fn(job.tile_ids, bufs[k], None)
+            if ev1 is not None:
+                ev1[i].record()
+            pending[k] = distributed.gather_to_root(job.send(k), parts=recv[k], async_op=True)
+        parts = None
+        for k in ((steps - 2) % 2, (steps - 1) % 2) if steps > 1 else (0,):
+            if pending[k] is not None:
+                parts = pending[k].wait()       # the last frame's gather is waited for last
         return parts
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)                            # same code path as the timed steps
     barrier()
     ds.read_counters(reset=True)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    # two accumulators in flight: the gather of frame i runs on RCCL's stream while the
-    # kernel of frame i+1 renders into the other buffer
-    bufs, recv = job.pipeline(2)
-    pending = [None, None]
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        k = i % 2
-        if pending[k] is not None:
-            pending[k].wait()               # the buffer's previous gather has read it
-        bufs[k].zero_()
-        # events bracket the tile kernel on the stream it is launched on (torch's current stream)
-        ev0[i].record()
-        job.render_fn(job.tile_ids, bufs[k], None)
-        ev1[i].record()
-        pending[k] = distributed.gather_to_root(bufs[k], parts=recv[k], async_op=True)
-    parts = None
-    for k in ((args.steps - 2) % 2, (args.steps - 1) % 2) if args.steps > 1 else (0,):
-        if pending[k] is not None:
-            parts = pending[k].wait()       # the last frame's gather is waited for last
+    parts = run(args.steps, ev0, ev1)
     barrier()
     elapsed = time.perf_counter() - t0
     counters = ds.read_counters(reset=True)

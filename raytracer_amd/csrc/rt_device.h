@@ -515,6 +515,20 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         const bool pack16 = walking && !small && count <= 16;
         const bool pack32 = walking && !small && !pack16 && count <= 32;
         const unsigned long long p16 = __ballot(pack16), p32 = __ballot(pack32);
+#ifdef RT_PHASE_TIMERS
+        if (SHADOW) {
+            // sharing statistics of packed leaves: rays, distinct leaves
+            unsigned long long rest = p16 | p32;
+            const unsigned long long n_rays = __popcll(rest);
+            unsigned long long n_leaves = 0;
+            while (rest) {
+                const int32_t lf = bcast_i(first, first_lane(rest));
+                rest &= ~__ballot((pack16 || pack32) && first == lf);
+                n_leaves++;
+            }
+            if (lane == 0 && n_rays) { atomicAdd(&g_phase_cycles[25], n_rays); atomicAdd(&g_phase_cycles[26], n_leaves); atomicAdd(&g_phase_cycles[27], 1ull); }
+        }
+#endif
         if (p16) packed_leaves<COUNT, SHADOW, 16>(S, flagged, p16, r, first, count, w, found, best);
         clk.lap(PH_PACK16);
         if (p32) packed_leaves<COUNT, SHADOW, 32>(S, flagged, p32, r, first, count, w, found, best);

@@ -125,13 +125,26 @@ class FrameJob(object):
         return gather_to_root(acc)
 
     def pipeline(self, depth=2):
-        """`depth` integer accumulators with their receive lists for frames in flight:
-        frame i renders into buffer i % depth while the gather of frame i-1 still runs."""
+        """`depth` integer accumulators with their wire buffers and receive lists for frames
+        in flight: frame i renders into buffer i % depth while the gather of frame i-1
+        still runs.  Returns (accumulators, receive lists); `send(slot)` packs a slot."""
         import torch
         bufs = [self.sum_rgb8] + [torch.zeros_like(self.sum_rgb8) for _ in range(depth - 1)]
+        self.pipe_bufs = bufs
+        self.pipe_clamped = [torch.zeros_like(b) for b in bufs]
+        self.pipe_wire = [torch.zeros(b.shape, dtype=torch.int32, device=b.device) for b in bufs]
         is_root = self.rank == 0 and self.world_size > 1
-        recv = [[torch.empty_like(b) for _ in range(self.world_size)] if is_root else None for b in bufs]
+        recv = [[torch.empty_like(w) for _ in range(self.world_size)] if is_root else None for w in self.pipe_wire]
         return bufs, recv
+
+    def send(self, slot):
+        """The slot's accumulator as it travels: int32 per channel (saturated), half the
+        bytes of the kernel's 64-bit sums.  A pixel's sum only leaves the int32 range when
+        samples were infinite, and such a pixel is clamped to 0 or 255 on arrival anyway."""
+        import torch
+        torch.clamp(self.pipe_bufs[slot], -2147483648, 2147483647, out=self.pipe_clamped[slot])
+        self.pipe_wire[slot].copy_(self.pipe_clamped[slot])
+        return self.pipe_wire[slot]
 
     def finish(self, parts):
         """On rank 0: the frame as uint8 (height, width, 3), by the rules of main.py:99-106

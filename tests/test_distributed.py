@@ -60,7 +60,7 @@ def _worker(rank, world_size, port, scene, overrides, out_path):
             pending[k].wait()
         bufs[k].zero_()
         job.render_fn(job.tile_ids, bufs[k], None)
-        pending[k] = distributed.gather_to_root(bufs[k], parts=recv[k], async_op=True)
+        pending[k] = distributed.gather_to_root(job.send(k), parts=recv[k], async_op=True)
     pending[1].wait()
     frame = job.finish(pending[0].wait())
     if rank == 0:

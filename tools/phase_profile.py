@@ -69,6 +69,8 @@ def main():
     if t[24]:
         out["boxed_shadow_sharing"] = {"episodes": t[24], "rays": t[20], "distinct_leaves": t[21],
                                        "ray_chunk_pairs": t[22], "distinct_leaf_chunk_pairs": t[23]}
+    if t[27]:
+        out["packed_shadow_sharing"] = {"episodes": t[27], "rays": t[25], "distinct_leaves": t[26]}
     print(json.dumps(out, indent=1))
 
 
