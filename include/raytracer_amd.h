@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 2
+#define RTAMD_ABI_VERSION 3
 
 enum {
     RTAMD_OK = 0,
@@ -275,6 +275,13 @@ typedef struct rtamd_scene_desc {
     int64_t n_texel_bytes;
     const rtamd_texture *textures;      /* device, NULL when n_textures == 0 */
     const uint8_t *texels;              /* device */
+    const double *chunk_tree;           /* device, optional: [n_chunks][12] = per chunk its box
+                                           (as chunk_boxes) and, for every fourth chunk of a
+                                           leaf counted from the leaf's first, the box around
+                                           that chunk and the next three of the same leaf
+                                           (zeros elsewhere): what a lane reads when it sorts
+                                           out which chunks of a leaf its own shadow ray can
+                                           touch.  NULL: leaf_boxes serves instead */
 } rtamd_scene_desc;
 
 /* Camera and view plane (camera.py:12-33, :142-146, :222-225; tracer.py:91-95). */

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(HERE, "csrc", "librtamd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_BRANCH_LEVELS = 8
 N_COUNTERS = 8
 COUNT_WORK = 1
@@ -82,7 +82,7 @@ class SceneDesc(C.Structure):
                 ("prim_normals", C.c_void_p), ("prim_normal_offset", C.c_void_p),
                 ("prim_material", C.c_void_p),
                 ("n_textures", C.c_int32), ("reserved", C.c_int32), ("n_texel_bytes", C.c_int64),
-                ("textures", C.c_void_p), ("texels", C.c_void_p)]
+                ("textures", C.c_void_p), ("texels", C.c_void_p), ("chunk_tree", C.c_void_p)]
 
 
 class Camera(C.Structure):

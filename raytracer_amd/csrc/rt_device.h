@@ -373,6 +373,19 @@ __device__ __forceinline__ bool box_touch(const double* bx, const Ray& q, V3 inv
     return !(tn > tf) && !(tf < 0.0);
 }
 
+// The same test reporting the exit distance.
+__device__ __forceinline__ bool box_touch_far(const double* bx, const Ray& q, V3 inv, double& tf) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* p = reinterpret_cast<const d2*>(bx);
+    const d2 a = p[0], b = p[1], c = p[2];
+    const double x0 = (a.x - q.o.x) * inv.x, x1 = (b.y - q.o.x) * inv.x;
+    const double y0 = (a.y - q.o.y) * inv.y, y1 = (c.x - q.o.y) * inv.y;
+    const double z0 = (b.x - q.o.z) * inv.z, z1 = (c.y - q.o.z) * inv.z;
+    const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+    tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+    return !(tn > tf) && !(tf < 0.0);
+}
+
 // KDTree.hit's scan of one boxed leaf (kdtree.py:169-173) by the lane that owns the ray:
 // chunk boxes, then the boxes of a touched chunk's 8-row cells, then the rows of a touched
 // cell.  A box the ray enters beyond the best t so far cannot hold a closer or equal hit.
@@ -559,20 +572,31 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
 #ifndef RT_NO_BOX_PREPASS
         const bool prepass = SHADOW && S.leaf_boxes != nullptr;
         if (prepass && walking && !small && cbase >= 0 && count <= 4096) {
-            typedef double d2 __attribute__((ext_vector_type(2)));
-            const double ix = 1.0 / r.d.x, iy = 1.0 / r.d.y, iz = 1.0 / r.d.z;
+            const V3 inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
             const int32_t nch = (count + 63) >> 6;
-            for (int32_t j = 0; j < nch; ++j) {
-                const d2* p = reinterpret_cast<const d2*>(S.leaf_boxes + (int64_t)(cbase + j) * 54);
-                const d2 a = p[0], b = p[1], c = p[2];
-                const double x0 = (a.x - r.o.x) * ix, x1 = (b.y - r.o.x) * ix;
-                const double y0 = (a.y - r.o.y) * iy, y1 = (c.x - r.o.y) * iy;
-                const double z0 = (b.x - r.o.z) * iz, z1 = (c.y - r.o.z) * iz;
-                const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
-                const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
-                if (!(tn > tf) && !(tf < 0.0)) {
-                    my_chunks |= 1ull << j;
-                    if (!(tf < limit)) my_any_hit_decides = false;
+            double tn;
+            if (S.chunk_tree != nullptr) {
+                // 96-byte rows: the chunk's box, then the box around a group of four chunks
+                // (in the row of the group's first chunk); a group the ray misses is skipped whole
+                const double* rec = S.chunk_tree + (int64_t)cbase * 12;
+                for (int32_t g = 0; g < nch; g += 4) {
+                    if (nch > 4 && !box_touch(rec + g * 12 + 6, r, inv, tn)) continue;
+                    const int32_t g_end = min(g + 4, nch);
+                    for (int32_t j = g; j < g_end; ++j) {
+                        double tf;
+                        if (box_touch_far(rec + j * 12, r, inv, tf)) {
+                            my_chunks |= 1ull << j;
+                            if (!(tf < limit)) my_any_hit_decides = false;
+                        }
+                    }
+                }
+            } else {
+                for (int32_t j = 0; j < nch; ++j) {
+                    double tf;
+                    if (box_touch_far(S.leaf_boxes + (int64_t)(cbase + j) * 54, r, inv, tf)) {
+                        my_chunks |= 1ull << j;
+                        if (!(tf < limit)) my_any_hit_decides = false;
+                    }
                 }
             }
         }

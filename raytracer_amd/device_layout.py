@@ -12,7 +12,9 @@ module
   * records each row's position in the reference order (`tri_order`), which the kernels
     use for every tie-break and first-in-order decision, and
   * gives every 64-row chunk an axis-aligned bounding box (`chunk_boxes`, padded), so a
-    wave can skip chunks a ray's line cannot touch.
+    wave can skip chunks a ray's line cannot touch; `chunk_tree` holds the same boxes row by
+    row together with a box around every group of four chunks of a leaf, for a lane that
+    sorts out the chunks its own ray can touch.
 
 The degenerate leaves of the reference's build (hundreds to 1340 triangles, a few per
 mesh, visited by most rays) are where almost all triangle tests are spent; skipping
@@ -27,6 +29,7 @@ from . import capi
 
 CHUNK = 64
 CELL = 8
+GROUP = 4           # chunks per group box in `chunk_tree`
 PAD = 1.0e-9
 
 
@@ -84,6 +87,17 @@ def device_arrays(flat):
                 rec[1 + k // CELL, 0:3], rec[1 + k // CELL, 3:6] = klo, khi
             leaf_boxes.append(rec)
             n_chunks += 1
+    # per chunk: its box, and for every GROUP-th chunk of a leaf the box around the group
+    chunk_tree = numpy.zeros((n_chunks, 12))
+    if n_chunks:
+        chunk_tree[:, 0:3], chunk_tree[:, 3:6] = numpy.array(boxes_lo), numpy.array(boxes_hi)
+        for node, count in zip(leaves[counts > CHUNK], counts[counts > CHUNK]):
+            c0 = int(nodes["split"][node])
+            nch = (int(count) + CHUNK - 1) // CHUNK
+            for s in range(0, nch, GROUP):
+                members = chunk_tree[c0 + s:c0 + min(s + GROUP, nch)]
+                chunk_tree[c0 + s, 6:9] = members[:, 0:3].min(axis=0)
+                chunk_tree[c0 + s, 9:12] = members[:, 3:6].max(axis=0)
     if n_chunks:
         chunk_boxes = numpy.ascontiguousarray(numpy.concatenate([numpy.array(boxes_lo).T, numpy.array(boxes_hi).T], axis=0))
     else:
@@ -97,6 +111,7 @@ def device_arrays(flat):
     a["tri_rows"] = rows.ravel()
     a["chunk_boxes"] = chunk_boxes.ravel()
     a["leaf_boxes"] = numpy.concatenate(leaf_boxes).ravel() if leaf_boxes else numpy.zeros(0)
+    a["chunk_tree"] = chunk_tree.ravel()
     a["kd_nodes"] = nodes.view(numpy.uint8)
     # node, left child, right child side by side: two levels of the walk per load
     triples = numpy.zeros((len(nodes), 4), dtype=nodes.dtype)

@@ -124,6 +124,8 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
     nodes = dev["kd_nodes"].view([("split", "<f8"), ("a", "<i4"), ("b", "<i4")])
     boxes = dev["chunk_boxes"].reshape(6, n_chunks)
     leaf_boxes = dev["leaf_boxes"].reshape(n_chunks, 9, 6)
+    chunk_tree = dev["chunk_tree"].reshape(n_chunks, 12)
+    assert numpy.array_equal(chunk_tree[:, :6].T, boxes)
     rows_aos = dev["tri_rows"].reshape(n, 10)
     assert numpy.array_equal(rows_aos[:, :9], geom.T)
     meta = numpy.ascontiguousarray(rows_aos[:, 9]).view(numpy.int32).reshape(n, 2)
@@ -137,6 +139,15 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
             assert nd["split"] < 0 and numpy.array_equal(rows, numpy.arange(first, first + count))
             continue
         base = int(nd["split"])
+        nch = (count + device_layout.CHUNK - 1) // device_layout.CHUNK
+        for j in range(nch):
+            # the group box of every fourth chunk encloses the boxes of its group; other rows hold zeros
+            if j % device_layout.GROUP == 0:
+                members = chunk_tree[base + j:base + min(j + device_layout.GROUP, nch)]
+                assert (chunk_tree[base + j, 6:9] <= members[:, 0:3]).all()
+                assert (chunk_tree[base + j, 9:12] >= members[:, 3:6]).all()
+            else:
+                assert not chunk_tree[base + j, 6:12].any()
         for c in range(0, count, device_layout.CHUNK):
             g = geom[:, first + c:first + min(c + device_layout.CHUNK, count)]
             pts = numpy.concatenate([g[0:3], g[0:3] + g[3:6], g[0:3] + g[6:9]], axis=1)
