@@ -281,7 +281,8 @@ typedef struct rtamd_scene_desc {
                                            that chunk and the next three of the same leaf
                                            (zeros elsewhere): what a lane reads when it sorts
                                            out which chunks of a leaf its own shadow ray can
-                                           touch.  NULL: leaf_boxes serves instead */
+                                           touch.  NULL: the wave tests the chunk boxes of one
+                                           ray at a time */
 } rtamd_scene_desc;
 
 /* Camera and view plane (camera.py:12-33, :142-146, :222-225; tracer.py:91-95). */

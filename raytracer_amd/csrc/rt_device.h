@@ -570,30 +570,20 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         unsigned long long my_chunks = 0;
         bool my_any_hit_decides = true;
 #ifndef RT_NO_BOX_PREPASS
-        const bool prepass = SHADOW && S.leaf_boxes != nullptr;
+        const bool prepass = SHADOW && S.chunk_tree != nullptr;
         if (prepass && walking && !small && cbase >= 0 && count <= 4096) {
             const V3 inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
             const int32_t nch = (count + 63) >> 6;
             double tn;
-            if (S.chunk_tree != nullptr) {
-                // 96-byte rows: the chunk's box, then the box around a group of four chunks
-                // (in the row of the group's first chunk); a group the ray misses is skipped whole
-                const double* rec = S.chunk_tree + (int64_t)cbase * 12;
-                for (int32_t g = 0; g < nch; g += 4) {
-                    if (nch > 4 && !box_touch(rec + g * 12 + 6, r, inv, tn)) continue;
-                    const int32_t g_end = min(g + 4, nch);
-                    for (int32_t j = g; j < g_end; ++j) {
-                        double tf;
-                        if (box_touch_far(rec + j * 12, r, inv, tf)) {
-                            my_chunks |= 1ull << j;
-                            if (!(tf < limit)) my_any_hit_decides = false;
-                        }
-                    }
-                }
-            } else {
-                for (int32_t j = 0; j < nch; ++j) {
+            // 96-byte rows: the chunk's box, then the box around a group of four chunks (in the
+            // row of the group's first chunk); a group the ray misses is skipped whole
+            const double* rec = S.chunk_tree + (int64_t)cbase * 12;
+            for (int32_t g = 0; g < nch; g += 4) {
+                if (nch > 4 && !box_touch(rec + g * 12 + 6, r, inv, tn)) continue;
+                const int32_t g_end = min(g + 4, nch);
+                for (int32_t j = g; j < g_end; ++j) {
                     double tf;
-                    if (box_touch_far(S.leaf_boxes + (int64_t)(cbase + j) * 54, r, inv, tf)) {
+                    if (box_touch_far(rec + j * 12, r, inv, tf)) {
                         my_chunks |= 1ull << j;
                         if (!(tf < limit)) my_any_hit_decides = false;
                     }

@@ -332,6 +332,8 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
         return fail(RTAMD_EINVAL, "kd-tree tables missing%s");
     if (d->leaf_boxes && (!d->tri_rows || !d->chunk_boxes || !d->tri_order))
         return fail(RTAMD_EINVAL, "leaf_boxes needs tri_rows, chunk_boxes and tri_order beside it%s");
+    if (d->chunk_tree && (!d->chunk_boxes || !d->tri_order))
+        return fail(RTAMD_EINVAL, "chunk_tree needs chunk_boxes and tri_order beside it%s");
     if (d->n_refs < 0 || d->n_refs * 72 > 0x7fffffffLL)
         return fail(RTAMD_EUNSUPPORTED, "more than 2^31 bytes of leaf triangle rows%s");
     if (d->ambient.kind != RTAMD_AMBIENT_CONSTANT && d->ambient.kind != RTAMD_AMBIENT_OCCLUDER)
