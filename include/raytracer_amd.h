@@ -283,6 +283,11 @@ typedef struct rtamd_scene_desc {
                                            out which chunks of a leaf its own shadow ray can
                                            touch.  NULL: the wave tests the chunk boxes of one
                                            ray at a time */
+    const double *leaf_aabb;            /* device, optional: [n_kd_nodes][6] = for a leaf of at most
+                                           64 rows the box around its triangles, lo.xyz hi.xyz
+                                           (conservative); zeros for other nodes.  A ray that
+                                           crosses the leaf's cell but misses this box skips
+                                           the leaf */
 } rtamd_scene_desc;
 
 /* Camera and view plane (camera.py:12-33, :142-146, :222-225; tracer.py:91-95). */

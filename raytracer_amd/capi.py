@@ -82,7 +82,8 @@ class SceneDesc(C.Structure):
                 ("prim_normals", C.c_void_p), ("prim_normal_offset", C.c_void_p),
                 ("prim_material", C.c_void_p),
                 ("n_textures", C.c_int32), ("reserved", C.c_int32), ("n_texel_bytes", C.c_int64),
-                ("textures", C.c_void_p), ("texels", C.c_void_p), ("chunk_tree", C.c_void_p)]
+                ("textures", C.c_void_p), ("texels", C.c_void_p), ("chunk_tree", C.c_void_p),
+                ("leaf_aabb", C.c_void_p)]
 
 
 class Camera(C.Structure):

@@ -449,6 +449,8 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     int32_t node = T.node_offset;
     const int lane = lane_id();
     const TriTable geom = tri_table(S);
+    const bool use_leaf_aabb = S.leaf_aabb != nullptr;
+    const V3 inv_d = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     PhaseClock clk;
     clk.start(SHADOW ? 8 : 0);
     clk.count(PH_QUERIES);
@@ -479,22 +481,47 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                     t_far = t;
                 }
             };
-            // a 64-byte record holds a node and both its children, so every load serves two levels
-            const rtamd_kdnode* rec = S.kd_triples + (int64_t)node * 4;
-            rtamd_kdnode nd = rec[0], left = rec[1], right = rec[2];
-            while ((nd.b & 3) != 3) {
-                const int32_t left_index = node + 1;
-                step(nd);
-                nd = node == left_index ? left : right;
-                if ((nd.b & 3) == 3) break;
-                step(nd);
-                rec = S.kd_triples + (int64_t)node * 4;
-                nd = rec[0]; left = rec[1]; right = rec[2];
+            // pops the far child pushed last; the far bound pushed with it = t of the entry
+            // now on top, or the root exit
+            auto pop = [&]() {
+                sp--;
+                if (sp < LDS_STACK) { node = stk.node[sp * 64 + lane]; t_near = stk.t[sp * 64 + lane]; }
+                else { node = deep_node[sp - LDS_STACK]; t_near = deep_t[sp - LDS_STACK]; }
+                if (sp == 0) t_far = t_exit;
+                else if (sp - 1 < LDS_STACK) t_far = stk.t[(sp - 1) * 64 + lane];
+                else t_far = deep_t[sp - 1 - LDS_STACK];
+            };
+            for (;;) {
+                // a 64-byte record holds a node and both its children, so every load serves two levels
+                const rtamd_kdnode* rec = S.kd_triples + (int64_t)node * 4;
+                rtamd_kdnode nd = rec[0], left = rec[1], right = rec[2];
+                while ((nd.b & 3) != 3) {
+                    const int32_t left_index = node + 1;
+                    step(nd);
+                    nd = node == left_index ? left : right;
+                    if ((nd.b & 3) == 3) break;
+                    step(nd);
+                    rec = S.kd_triples + (int64_t)node * 4;
+                    nd = rec[0]; left = rec[1]; right = rec[2];
+                }
+                w.leaf();
+                first = nd.a;
+                count = nd.b >> 2;
+                cbase = S.chunk_boxes ? (int32_t)nd.split : -1;
+#ifndef RT_NO_LEAF_AABB
+                // a leaf of up to 64 rows whose triangles' box the ray misses holds no hit: the
+                // lane walks on at once (not when counting: the reference tests the rows)
+                if (!COUNT && use_leaf_aabb && count <= 64) {
+                    double tn;
+                    if (count == 0 || !box_touch(S.leaf_aabb + (int64_t)node * 6, r, inv_d, tn)) {
+                        if (sp == 0) { walking = false; first = 0; count = 0; cbase = -1; break; }
+                        pop();
+                        continue;
+                    }
+                }
+#endif
+                break;
             }
-            w.leaf();
-            first = nd.a;
-            count = nd.b >> 2;
-            cbase = S.chunk_boxes ? (int32_t)nd.split : -1;
         }
 
         clk.lap(PH_DESCENT);
@@ -572,7 +599,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
 #ifndef RT_NO_BOX_PREPASS
         const bool prepass = SHADOW && S.chunk_tree != nullptr;
         if (prepass && walking && !small && cbase >= 0 && count <= 4096) {
-            const V3 inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+            const V3 inv = inv_d;
             const int32_t nch = (count + 63) >> 6;
             double tn;
             // 96-byte rows: the chunk's box, then the box around a group of four chunks (in the

@@ -112,6 +112,20 @@ def device_arrays(flat):
     a["chunk_boxes"] = chunk_boxes.ravel()
     a["leaf_boxes"] = numpy.concatenate(leaf_boxes).ravel() if leaf_boxes else numpy.zeros(0)
     a["chunk_tree"] = chunk_tree.ravel()
+    # box around the triangles of every leaf of at most CHUNK rows (bigger leaves have chunk boxes)
+    leaf_aabb = numpy.zeros((len(nodes), 6))
+    small = leaves[(counts > 0) & (counts <= CHUNK)]
+    if len(small):
+        first = nodes["a"][small].astype(numpy.int64)
+        cnt = counts[(counts > 0) & (counts <= CHUNK)].astype(numpy.int64)
+        row = numpy.repeat(first, cnt) + (numpy.arange(cnt.sum()) - numpy.repeat(numpy.cumsum(cnt) - cnt, cnt))
+        seg = numpy.cumsum(cnt) - cnt
+        v0 = geom[0:3, row]
+        v1, v2 = v0 + geom[3:6, row], v0 + geom[6:9, row]
+        lo = numpy.minimum.reduceat(numpy.minimum(numpy.minimum(v0, v1), v2), seg, axis=1).T
+        hi = numpy.maximum.reduceat(numpy.maximum(numpy.maximum(v0, v1), v2), seg, axis=1).T
+        leaf_aabb[small, 0:3], leaf_aabb[small, 3:6] = _padded(lo, hi)
+    a["leaf_aabb"] = leaf_aabb.ravel()
     a["kd_nodes"] = nodes.view(numpy.uint8)
     # node, left child, right child side by side: two levels of the walk per load
     triples = numpy.zeros((len(nodes), 4), dtype=nodes.dtype)

@@ -56,6 +56,7 @@ class DeviceScene(object):
             desc.leaf_boxes = self.tensors["leaf_boxes"].data_ptr()
             desc.chunk_boxes = self.tensors["chunk_boxes"].data_ptr()
             desc.chunk_tree = self.tensors["chunk_tree"].data_ptr()
+            desc.leaf_aabb = self.tensors["leaf_aabb"].data_ptr()
             desc.n_chunks = n_chunks
             handle = C.c_void_p()
             capi.check(self.lib.rtamd_scene_create(C.byref(desc), C.byref(handle)), self.lib)

@@ -131,8 +131,18 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
     meta = numpy.ascontiguousarray(rows_aos[:, 9]).view(numpy.int32).reshape(n, 2)
     assert numpy.array_equal(meta[:, 0], dev["tri_prim"]) and numpy.array_equal(meta[:, 1], order)
     seen = 0
-    for nd in nodes[(nodes["b"] & 3) == 3]:
+    leaf_aabb = dev["leaf_aabb"].reshape(len(nodes), 6)
+    assert not leaf_aabb[(nodes["b"] & 3) != 3].any()
+    for index in numpy.nonzero((nodes["b"] & 3) == 3)[0]:
+        nd = nodes[index]
         first, count = int(nd["a"]), int(nd["b"]) >> 2
+        if 0 < count <= device_layout.CHUNK:
+            # every triangle of a small leaf lies inside the leaf's box
+            g = geom[:, first:first + count]
+            pts = numpy.concatenate([g[0:3], g[0:3] + g[3:6], g[0:3] + g[6:9]], axis=1)
+            assert (pts.min(axis=1) > leaf_aabb[index, 0:3]).all() and (pts.max(axis=1) < leaf_aabb[index, 3:6]).all()
+        else:
+            assert not leaf_aabb[index].any()
         rows = order[first:first + count]
         assert rows.min() == first and rows.max() == first + count - 1      # stays inside its leaf
         if count <= device_layout.CHUNK:
