@@ -247,10 +247,14 @@ constexpr int LDS_STACK = 10;
 struct KdStack {
     int32_t* node;      // LDS, [LDS_STACK][64]
     double* t;          // LDS, [LDS_STACK][64]
+    int32_t* slot;      // LDS, [64]: lane ids by rank while walks are handed over (see kd_query_wave)
 };
 #define RT_KD_STACK_LDS_BYTES (LDS_STACK * 64 * 12)
 #ifndef RT_SMALL_LEAF
 #define RT_SMALL_LEAF 0
+#endif
+#ifndef RT_STEAL_MIN_PAIRS
+#define RT_STEAL_MIN_PAIRS 2      // hand walks over only when at least this many lanes can take one (1: 17.72, 4: 17.81, 12: 18.36, never: 18.19 ms)
 #endif
 constexpr int SMALL_LEAF = RT_SMALL_LEAF;     // leaves up to this size are scanned by the lane that reached them
 
@@ -429,10 +433,13 @@ __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& 
 // with a hit.  SHADOW = true is KDTree.shadow_hit (kdtree.py:157-164): the first item in
 // leaf order that reports a hit ends the query and its t is returned.
 template <bool COUNT, bool SHADOW>
-__device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool active, const Ray& r,
-                              double limit, bool coherent, const KdStack& stk, Work<COUNT>& w, bool& found,
+__device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool active, const Ray& ray_in,
+                              double limit_in, bool coherent, const KdStack& stk, Work<COUNT>& w, bool& found,
                               TriHit& best) {
     found = false;
+    // a lane may come to walk part of another lane's ray (see "handing over" below)
+    Ray r = ray_in;
+    double limit = limit_in;
     // rows carry a does-not-cast-shadows bit; the tree says whether any row has it, so
     // that the usual mesh (all rows cast) never loads the flags, and a mesh that casts no
     // shadow at all is not walked (its walk is still counted when COUNT asks for the
@@ -450,12 +457,68 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     const int lane = lane_id();
     const TriTable geom = tri_table(S);
     const bool use_leaf_aabb = S.leaf_aabb != nullptr;
-    const V3 inv_d = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    V3 inv_d = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+#ifndef RT_NO_STEAL
+    constexpr bool STEAL = SHADOW && !COUNT;
+#else
+    constexpr bool STEAL = false;
+#endif
+    // Handing over.  A shadow ray whose every possible hit lies before its limit (no limit,
+    // or the ray leaves the root box before it) is occluded exactly when any triangle on it
+    // is hit, whichever part of the walk finds it.  Lanes whose own query is answered take
+    // over the bottom stack entry - the farthest, largest pending subtree - of a lane still
+    // walking such a ray and walk it as a query of their own; a hit by any part answers
+    // the ray's owner and ends all its parts.  `sb` is the bottom of the lane's stack,
+    // `owner` the lane whose ray this lane walks, out_* the answer to the lane's own ray.
+    int sb = 0;
+    int owner = lane;
+    bool out_found = false;
+    double out_t = 0;
+    bool steal_ok = STEAL && walking && (t_exit * (1.0 + 1e-9) + 1e-9 < limit);
     PhaseClock clk;
     clk.start(SHADOW ? 8 : 0);
     clk.count(PH_QUERIES);
 
     while (__ballot(walking)) {
+        if (STEAL) {
+            const unsigned long long idle_m = ~__ballot(walking);
+            const bool can_give = walking && steal_ok && sp > sb;
+            const unsigned long long donor_m = __ballot(can_give);
+            const int n_pairs = min((int)__popcll(idle_m), (int)__popcll(donor_m));
+            if (n_pairs >= RT_STEAL_MIN_PAIRS) {
+                const int rank_idle = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                const int rank_donor = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(donor_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donor_m, 0u));
+                const bool gives = can_give && rank_donor < n_pairs;
+                const bool takes = !walking && rank_idle < n_pairs;
+                if (gives) stk.slot[rank_donor] = lane;
+                __syncthreads();                    // one wave per workgroup: orders the LDS write and read
+                int src = lane;
+                if (takes) src = stk.slot[rank_idle];
+                __syncthreads();
+                int32_t g_node = 0;
+                double g_t = 0, g_exit = 0;
+                if (gives) {
+                    if (sb < LDS_STACK) { g_node = stk.node[sb * 64 + lane]; g_t = stk.t[sb * 64 + lane]; }
+                    else { g_node = deep_node[sb - LDS_STACK]; g_t = deep_t[sb - LDS_STACK]; }
+                    g_exit = t_exit;
+                    t_exit = g_t;                   // what remains with the giver now ends where the given part begins
+                    sb++;
+                }
+                const V3 no = v3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
+                const V3 nd = v3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
+                const double n_limit = __shfl(limit, src);
+                const int n_owner = __shfl(owner, src);
+                const int32_t n_node = __shfl(g_node, src);
+                const double n_t = __shfl(g_t, src), n_exit = __shfl(g_exit, src);
+                if (takes) {
+                    r.o = no; r.d = nd; limit = n_limit; owner = n_owner;
+                    inv_d = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+                    node = n_node; t_near = n_t; t_far = n_exit; t_exit = n_exit;
+                    sp = 0; sb = 0;
+                    found = false; walking = true; steal_ok = true;
+                }
+            }
+        }
         int32_t first = 0, count = 0, cbase = -1;
         if (walking) {
             // One interior step of KDTree.iterate_nodes (kdtree.py:140-153) at `node`, whose
@@ -487,7 +550,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 sp--;
                 if (sp < LDS_STACK) { node = stk.node[sp * 64 + lane]; t_near = stk.t[sp * 64 + lane]; }
                 else { node = deep_node[sp - LDS_STACK]; t_near = deep_t[sp - LDS_STACK]; }
-                if (sp == 0) t_far = t_exit;
+                if (sp == sb) t_far = t_exit;
                 else if (sp - 1 < LDS_STACK) t_far = stk.t[(sp - 1) * 64 + lane];
                 else t_far = deep_t[sp - 1 - LDS_STACK];
             };
@@ -514,7 +577,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 if (!COUNT && use_leaf_aabb && count <= 64) {
                     double tn;
                     if (count == 0 || !box_touch(S.leaf_aabb + (int64_t)node * 6, r, inv_d, tn)) {
-                        if (sp == 0) { walking = false; first = 0; count = 0; cbase = -1; break; }
+                        if (sp == sb) { walking = false; first = 0; count = 0; cbase = -1; break; }
                         pop();
                         continue;
                     }
@@ -858,21 +921,34 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
             clk.lap(qbox >= 0 ? PH_BIG_BOXES : PH_BIG_PLAIN);
         }
 
+        if (STEAL) {
+            // a hit answers the ray's owner and ends every lane that walks a part of that ray
+            unsigned long long hits = __ballot(walking && found);
+            while (hits) {
+                const int h = first_lane(hits);
+                const int o = bcast_i(owner, h);
+                const double ht = bcast_d(best.t, h);
+                if (walking && owner == o) walking = false;
+                if (lane == o) { out_found = true; out_t = ht; }
+                hits &= __ballot(walking && found);
+            }
+        }
         if (walking) {
-            if (found || sp == 0) {
+            if ((!STEAL && found) || sp == sb) {
                 walking = false;
             } else {
                 sp--;
                 if (sp < LDS_STACK) { node = stk.node[sp * 64 + lane]; t_near = stk.t[sp * 64 + lane]; }
                 else { node = deep_node[sp - LDS_STACK]; t_near = deep_t[sp - LDS_STACK]; }
                 // the far bound pushed with this entry = t of the entry now on top, or the root exit
-                if (sp == 0) t_far = t_exit;
+                if (sp == sb) t_far = t_exit;
                 else if (sp - 1 < LDS_STACK) t_far = stk.t[(sp - 1) * 64 + lane];
                 else t_far = deep_t[sp - 1 - LDS_STACK];
             }
         }
         clk.lap(PH_POP);
     }
+    if (STEAL) { found = out_found; best.t = out_t; }
 }
 
 // ---------------------------------------------------------------- analytic primitives

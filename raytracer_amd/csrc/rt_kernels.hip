@@ -181,9 +181,11 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         // the wave's kd traversal stack (one wave per workgroup)
         __shared__ double stack_t[TREES ? LDS_STACK * 64 : 1];
         __shared__ int32_t stack_node[TREES ? LDS_STACK * 64 : 1];
+        __shared__ int32_t stack_slot[TREES ? 64 : 1];
         KdStack stk;
         stk.node = stack_node;
         stk.t = stack_t;
+        stk.slot = stack_slot;
         const V3 c = trace_wave<COUNT, EXT, TREES>(S, stk, live, ray, A.depth0, dr, work, first);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
