@@ -253,8 +253,18 @@ struct KdStack {
 #ifndef RT_SMALL_LEAF
 #define RT_SMALL_LEAF 0
 #endif
+// Shadow queries keep their rounds short so that lanes do not wait for the one with the
+// longest walk and idle lanes can be handed part of it.  1080p dragon frame: skips 1: 15.95,
+// 2: 16.46, 4: 17.20, 8: 17.79, unbounded 18.03 ms; node loads unbounded 15.97, 4: 15.76,
+// 2: 15.77, 1: 16.43 ms.
+#ifndef RT_MAX_SKIPS
+#define RT_MAX_SKIPS 1            // leaves a lane may skip by their boxes before its round ends
+#endif
+#ifndef RT_MAX_LOADS
+#define RT_MAX_LOADS 3            // node records a lane may load on the way down before its round ends
+#endif
 #ifndef RT_STEAL_MIN_PAIRS
-#define RT_STEAL_MIN_PAIRS 2      // hand walks over only when at least this many lanes can take one (1: 17.72, 4: 17.81, 12: 18.36, never: 18.19 ms)
+#define RT_STEAL_MIN_PAIRS 1      // hand walks over only when at least this many lanes can take one (1: 17.72, 4: 17.81, 12: 18.36, never: 18.19 ms)
 #endif
 constexpr int SMALL_LEAF = RT_SMALL_LEAF;     // leaves up to this size are scanned by the lane that reached them
 
@@ -519,7 +529,16 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 }
             }
         }
+#ifdef RT_PHASE_TIMERS
+        if (SHADOW) {
+            // descent rounds and the lanes walking in them
+            const unsigned long long n_walking = __popcll(__ballot(walking));
+            if (lane == 0) { atomicAdd(&g_phase_cycles[28], 1ull); atomicAdd(&g_phase_cycles[29], n_walking); }
+        }
+#endif
         int32_t first = 0, count = 0, cbase = -1;
+        bool parked = false;
+        int skips = 0, loads = 0;
         if (walking) {
             // One interior step of KDTree.iterate_nodes (kdtree.py:140-153) at `node`, whose
             // record is nd: picks the next node and pushes the far child where the ray
@@ -564,9 +583,12 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                     nd = node == left_index ? left : right;
                     if ((nd.b & 3) == 3) break;
                     step(nd);
+                    // a long descent ends the lane's round at an interior node (same reason as RT_MAX_SKIPS)
+                    if (STEAL && ++loads >= RT_MAX_LOADS) { parked = true; break; }
                     rec = S.kd_triples + (int64_t)node * 4;
                     nd = rec[0]; left = rec[1]; right = rec[2];
                 }
+                if (parked) break;
                 w.leaf();
                 first = nd.a;
                 count = nd.b >> 2;
@@ -579,6 +601,10 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                     if (count == 0 || !box_touch(S.leaf_aabb + (int64_t)node * 6, r, inv_d, tn)) {
                         if (sp == sb) { walking = false; first = 0; count = 0; cbase = -1; break; }
                         pop();
+                        // a long run of skipped leaves ends the lane's round without a leaf, so
+                        // that the wave's other lanes do not wait for it and part of its walk
+                        // can be handed over
+                        if (STEAL && ++skips >= RT_MAX_SKIPS) { parked = true; break; }
                         continue;
                     }
                 }
@@ -588,10 +614,11 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         }
 
         clk.lap(PH_DESCENT);
+        const bool at_leaf = walking && !parked;     // has a leaf to test in this round
         // rays of one tile that have not bounced yet run close together: their lanes reach
         // the same leaves and read the same rows, so each lane scans its own leaf; rays
         // that have scattered are tested by the wave together (packed and chunk steps below)
-        const bool small = walking && (lane_scans ? cbase < 0 : count <= SMALL_LEAF);
+        const bool small = at_leaf && (lane_scans ? cbase < 0 : count <= SMALL_LEAF);
         if (small) {
             if (SHADOW) {
                 for (int32_t i = 0; i < count; ++i) {
@@ -615,8 +642,8 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
 
         // leaves of up to 16 / 32 rows: four / two rays per step (an 8-row class with eight
         // rays per step measured no faster: 2153 vs 2185 Mrays/s)
-        const bool pack16 = walking && !small && count <= 16;
-        const bool pack32 = walking && !small && !pack16 && count <= 32;
+        const bool pack16 = at_leaf && !small && count <= 16;
+        const bool pack32 = at_leaf && !small && !pack16 && count <= 32;
         const unsigned long long p16 = __ballot(pack16), p32 = __ballot(pack32);
 #ifdef RT_PHASE_TIMERS
         if (SHADOW) {
@@ -637,11 +664,11 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         if (p32) packed_leaves<COUNT, SHADOW, 32>(S, flagged, p32, r, first, count, w, found, best);
         clk.lap(PH_PACK32);
 
-        unsigned long long big = __ballot(walking && !small && count > 32);
+        unsigned long long big = __ballot(at_leaf && !small && count > 32);
 #ifndef RT_NO_LANE_BOXED
         if (lane_scans) {
             // boxed leaves as well: each lane scans its own leaf through the cell boxes
-            const bool mine = walking && !small && count > 32 && cbase >= 0;
+            const bool mine = at_leaf && !small && count > 32 && cbase >= 0;
             const unsigned long long pm = __ballot(mine);
             if (pm) {
                 if (mine) {
@@ -661,7 +688,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         bool my_any_hit_decides = true;
 #ifndef RT_NO_BOX_PREPASS
         const bool prepass = SHADOW && S.chunk_tree != nullptr;
-        if (prepass && walking && !small && cbase >= 0 && count <= 4096) {
+        if (prepass && at_leaf && !small && cbase >= 0 && count <= 4096) {
             const V3 inv = inv_d;
             const int32_t nch = (count + 63) >> 6;
             double tn;
@@ -691,7 +718,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         // before its limit is decided by any hit (see below); the others keep the hit with
         // the earliest scan position over all their chunks, as KDTree.shadow_hit reports it.
         if (SHADOW && !COUNT && prepass) {
-            const bool eligible = walking && !small && count > 32 && (cbase < 0 ? count <= 64 : count <= 4096);
+            const bool eligible = at_leaf && !small && count > 32 && (cbase < 0 ? count <= 64 : count <= 4096);
             if (eligible && cbase < 0) { my_chunks = 1; my_any_hit_decides = false; }
             const bool has_work = eligible && my_chunks != 0;
             unsigned long long rest = __ballot(has_work);
@@ -759,12 +786,12 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
 #ifdef RT_PHASE_TIMERS
         if (SHADOW && prepass) {
             // sharing statistics of boxed leaves: rays, distinct leaves, (ray, chunk) pairs, distinct (leaf, chunk) pairs
-            unsigned long long rest = __ballot(walking && !small && count > 32 && cbase >= 0);
+            unsigned long long rest = __ballot(at_leaf && !small && count > 32 && cbase >= 0);
             unsigned long long n_rays = __popcll(rest), n_leaves = 0, n_pairs = 0, n_distinct = 0;
             while (rest) {
                 const int s0 = first_lane(rest);
                 const int32_t lf = bcast_i(first, s0);
-                unsigned long long same = __ballot(walking && !small && count > 32 && cbase >= 0 && first == lf);
+                unsigned long long same = __ballot(at_leaf && !small && count > 32 && cbase >= 0 && first == lf);
                 rest &= ~same;
                 n_leaves++;
                 unsigned long long uni = 0;
@@ -933,7 +960,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 hits &= __ballot(walking && found);
             }
         }
-        if (walking) {
+        if (walking && !parked) {
             if ((!STEAL && found) || sp == sb) {
                 walking = false;
             } else {
