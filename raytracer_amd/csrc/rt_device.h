@@ -93,7 +93,21 @@ __device__ __forceinline__ void draw_square(const rtamd_scene_desc& S, int sid, 
 }
 
 // ---------------------------------------------------------------- work counters
-template <bool COUNT> struct Work {
+#ifdef RT_PHASE_TIMERS
+__device__ unsigned long long g_phase_cycles[32];
+// coarse marks along a wave's life (profiling builds): cycles since the previous mark go to `slot`
+struct WaveMarks {
+    long long mark_t = 0;
+    __device__ __forceinline__ void mark(int slot) {
+        const long long now = clock64();
+        if (__lane_id() == 0) atomicAdd(&g_phase_cycles[slot], (unsigned long long)(now - mark_t));
+        mark_t = clock64();
+    }
+};
+#else
+struct WaveMarks { __device__ __forceinline__ void mark(int) {} };
+#endif
+template <bool COUNT> struct Work : WaveMarks {
     uint32_t closest = 0, shadow = 0;
     __device__ __forceinline__ void node() {}
     __device__ __forceinline__ void leaf() {}
@@ -104,7 +118,7 @@ template <bool COUNT> struct Work {
     __device__ __forceinline__ uint32_t tris() const { return 0; }
     __device__ __forceinline__ uint32_t analytics() const { return 0; }
 };
-template <> struct Work<true> {
+template <> struct Work<true> : WaveMarks {
     uint32_t closest = 0, shadow = 0, n_node = 0, n_leaf = 0, n_tri = 0, n_analytic = 0;
     __device__ __forceinline__ void node() { n_node++; }
     __device__ __forceinline__ void leaf() { n_leaf++; }
@@ -214,7 +228,6 @@ __device__ __forceinline__ TriRow load_row(const rtamd_scene_desc& S, int32_t re
 // kd query to a global table (closest-hit queries in slots 0-7, shadow queries in 8-15,
 // whole waves in slot 16); tools/phase_profile.py builds such a library and prints the split.
 #ifdef RT_PHASE_TIMERS
-__device__ unsigned long long g_phase_cycles[32];
 struct PhaseClock {
     long long last;
     int base;
@@ -1277,7 +1290,9 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
         sr.o = h.p;
         sr.d = v3(0, 0, 1);
         if (lit) sr.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
+        w.mark(30);
         if (occluded_wave<COUNT, TREES>(S, stk, lit, sr, false, 0.0, w)) amb = ld3(S.ambient.occluded);
+        w.mark(18);     // ambient occlusion query, kd query included
     }
     const bool textured = EXT && m.kind == RTAMD_SV_MATTE;
     V3 L = (textured ? ld3(m.ambient) * tex : ld3(m.ambient)) * amb;
@@ -1319,7 +1334,9 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
             if (lt.kind == RTAMD_POINT) limit = norm(sr.o - ld3(lt.position));                    // light.py:32
             else if (lt.kind == RTAMD_AREA) limit = dot(sample_point - sr.o, sr.d);               // light.py:125
             const bool bounded = lt.kind == RTAMD_POINT || lt.kind == RTAMD_AREA;
+            w.mark(30);
             if (__ballot(facing)) in_shadow = occluded_wave<COUNT, TREES>(S, stk, facing, sr, bounded, limit, w);
+            w.mark(19);     // light shadow query, kd query included
         }
         if (!facing || in_shadow || !gate) continue;
         V3 f = ld3(m.diffuse);
@@ -1413,7 +1430,9 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
         }
         Hit h;
         h.p = v3(0, 0, 0); h.n = v3(0, 0, 1); h.material = 0;
+        w.mark(30);     // ray generation / previous bounce
         const bool hit = closest_hit_wave<COUNT, TREES>(S, stk, alive, primary, ray, w, h);
+        w.mark(31);     // closest hit, kd query included
         if (alive && !hit) { L = L + W * background; alive = false; }
         if (alive && primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; }
         primary = false;

@@ -101,6 +101,9 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
     const int64_t k = wave * BLOCK + threadIdx.x;
     bool live = k < A.n;
     Work<COUNT> work;
+#ifdef RT_PHASE_TIMERS
+    work.mark_t = wave_start;
+#endif
     int64_t acc_row = -1;
     int64_t ko = k;             // row of this sample in the per-sample outputs
 
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
     }
 
 #ifdef RT_PHASE_TIMERS
+    work.mark(30);
     if (threadIdx.x == 0) {
         atomicAdd(&g_phase_cycles[16], (unsigned long long)(clock64() - wave_start));
         atomicAdd(&g_phase_cycles[17], 1ull);

@@ -71,6 +71,8 @@ def main():
                                        "ray_chunk_pairs": t[22], "distinct_leaf_chunk_pairs": t[23]}
     if t[27]:
         out["packed_shadow_sharing"] = {"episodes": t[27], "rays": t[25], "distinct_leaves": t[26]}
+    out["marks_inclusive"] = {"closest_hit_incl_kd": t[31] / float(total), "ambient_occlusion_incl_kd": t[18] / float(total),
+                              "light_shadow_incl_kd": t[19] / float(total), "everything_between": t[30] / float(total)}
     if t[28]:
         out["shadow_rounds"] = {"rounds": t[28], "lanes_walking_per_round": t[29] / float(t[28])}
     print(json.dumps(out, indent=1))
