@@ -479,7 +479,9 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     int32_t node = T.node_offset;
     const int lane = lane_id();
     const TriTable geom = tri_table(S);
-    const bool use_leaf_aabb = S.leaf_aabb != nullptr;
+    // leaf boxes pay in trees with many leaves along a ray; a tree of a few levels (the Cornell
+    // box: 9 nodes) is walked faster without them
+    const bool use_leaf_aabb = S.leaf_aabb != nullptr && T.depth >= 8;
     V3 inv_d = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
 #ifndef RT_NO_STEAL
     constexpr bool STEAL = SHADOW && !COUNT;
