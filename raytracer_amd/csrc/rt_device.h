@@ -276,6 +276,9 @@ struct KdStack {
 #ifndef RT_MAX_LOADS
 #define RT_MAX_LOADS 3            // node records a lane may load on the way down before its round ends
 #endif
+#ifndef RT_STEAL_PASSES
+#define RT_STEAL_PASSES 1         // hand-over passes per round (a giver gives one stack entry per pass)
+#endif
 #ifndef RT_STEAL_MIN_PAIRS
 #define RT_STEAL_MIN_PAIRS 1      // hand walks over only when at least this many lanes can take one (1: 17.72, 4: 17.81, 12: 18.36, never: 18.19 ms)
 #endif
@@ -505,12 +508,13 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     clk.count(PH_QUERIES);
 
     while (__ballot(walking)) {
-        if (STEAL) {
+        for (int pass = 0; STEAL && pass < RT_STEAL_PASSES; ++pass) {
             const unsigned long long idle_m = ~__ballot(walking);
             const bool can_give = walking && steal_ok && sp > sb;
             const unsigned long long donor_m = __ballot(can_give);
             const int n_pairs = min((int)__popcll(idle_m), (int)__popcll(donor_m));
-            if (n_pairs >= RT_STEAL_MIN_PAIRS) {
+            if (n_pairs < RT_STEAL_MIN_PAIRS) break;
+            {
                 const int rank_idle = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
                 const int rank_donor = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(donor_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donor_m, 0u));
                 const bool gives = can_give && rank_donor < n_pairs;
