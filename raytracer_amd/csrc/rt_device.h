@@ -1369,7 +1369,19 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
     return L;
 }
 
-struct Primary { int32_t object, prim; double t; };
+// Where the primary hit of a sample is reported (object, primitive, distance): written as
+// soon as it is known, so that it does not ride in registers through the shadow queries.
+struct Primary {
+    int32_t* object;
+    int32_t* prim;
+    double* t;
+    int64_t row;
+    __device__ __forceinline__ void put(int32_t o, int32_t p, double tt) const {
+        if (object) object[row] = o;
+        if (prim) prim[row] = p;
+        if (t) t[row] = tt;
+    }
+};
 
 // A child ray of a Transparent / Dielectric hit that waits while its sibling's subtree is
 // traced: ray, product of the weights down to it, and Dielectric's colour filter, which is
@@ -1408,12 +1420,13 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(pow(b.x, e), pow(
 // in-trace draw counter advances exactly as in the recursive formulation.
 template <bool COUNT, bool EXT, bool TREES>
 __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
-                         Work<COUNT>& w, Primary& first) {
+                         Work<COUNT>& w, const Primary& first) {
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
     const bool shade_kind = S.tracer_kind == RTAMD_TRACER_SHADE || S.tracer_kind == RTAMD_TRACER_WHITTED;
     const V3 background = shade_kind ? ld3(S.background) : v3(0, 0, 0);
     const bool area = S.tracer_kind == RTAMD_TRACER_AREA;
-    first.object = -1; first.prim = -1; first.t = 0;
+    const bool sample_lane = alive;
+    if (sample_lane) first.put(-1, -1, 0.0);
     bool primary = true;
     PendingRay pending[EXT ? RTAMD_MAX_BRANCH_LEVELS : 1];
     int n_pending = 0;
@@ -1440,7 +1453,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
         const bool hit = closest_hit_wave<COUNT, TREES>(S, stk, alive, primary, ray, w, h);
         w.mark(31);     // closest hit, kd query included
         if (alive && !hit) { L = L + W * background; alive = false; }
-        if (alive && primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; }
+        if (alive && primary) first.put(h.object, h.prim, h.t);
         primary = false;
         if (EXT && alive && has_filter) { W = W * powv(filter, h.t); has_filter = false; }
         const rtamd_material& m = S.materials[alive ? h.material : 0];

@@ -60,6 +60,40 @@ struct LaunchArgs {
     unsigned long long* counters;
 };
 
+// Tile mode: sample k = (tile position, wave inside the tile, lane).  A wave holds a square
+// block of the tile's pixels at 2^group_shift consecutive sample indices each: 8x8 pixels x 1
+// sample, 4x4 x 4, 2x2 x 16 or 1 pixel x 64.  Smaller blocks keep the hit points of a wave -
+// the origins of its shadow rays - closer together.
+struct TileSlot {
+    int32_t col, row, soff;
+    int64_t acc_row;        // row of the pixel in the tile-compact accumulators
+    int64_t ko;             // row of the sample in the per-sample outputs: (tile, sample, pixel in tile) order
+};
+__device__ __forceinline__ TileSlot tile_slot(const LaunchArgs& A, int64_t k) {
+    const int32_t lane = (int32_t)(k & 63);
+    const int64_t q = k >> 6;
+    const int32_t waves_per_tile = A.n_samples;             // 64 * n_samples / 64
+    const int32_t wv = (int32_t)(q % waves_per_tile);
+    const int64_t tpos = q / waves_per_tile;
+    const int32_t g = A.group_shift;
+    const int32_t side_shift = 3 - (g >> 1);                // block side = 8, 4, 2, 1 pixels
+    const int32_t block = wv & ((1 << g) - 1);              // blocks per tile = 64 / side^2 = 2^g
+    const int32_t sgroup = wv >> g;
+    const int32_t in_block = lane & ((64 >> g) - 1);
+    const int32_t bx = block & ((8 >> side_shift) - 1), by = block >> (3 - side_shift);
+    const int32_t px = (bx << side_shift) + (in_block & ((1 << side_shift) - 1));
+    const int32_t py = (by << side_shift) + (in_block >> side_shift);
+    const int32_t pix = py * 8 + px;
+    const int32_t tile = A.tile_ids[tpos];
+    TileSlot ts;
+    ts.soff = (sgroup << g) + (lane >> (6 - g));
+    ts.col = (tile % A.tiles_x) * 8 + (pix & 7);
+    ts.row = (tile / A.tiles_x) * 8 + (pix >> 3);
+    ts.acc_row = tpos * 64 + pix;
+    ts.ko = (tpos * A.n_samples + ts.soff) * 64 + pix;
+    return ts;
+}
+
 // PinholeCamera.ray_direction (camera.py:31-33) / ThinLensCamera.ray_direction (:222-225)
 __device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point, V3 lens_point) {
     Ray r;
@@ -121,36 +155,15 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
             const V3 lens = A.cam.thin_lens ? ld3(A.b3 + 3 * k) : v3(0, 0, 0);
             ray = camera_ray(A.cam, ld3(A.a3 + 3 * k), lens);
         } else {
-            // sample k = (tile position, wave inside the tile, lane).  A wave holds a square
-            // block of the tile's pixels at 2^group_shift consecutive sample indices each:
-            // 8x8 pixels x 1 sample, 4x4 x 4, 2x2 x 16 or 1 pixel x 64.  Smaller blocks keep
-            // the hit points of a wave - the origins of its shadow rays - closer together.
-            const int32_t lane = (int32_t)(k & 63);
-            const int64_t q = k >> 6;
-            const int32_t waves_per_tile = A.n_samples;             // 64 * n_samples / 64
-            const int32_t wv = (int32_t)(q % waves_per_tile);
-            const int64_t tpos = q / waves_per_tile;
-            const int32_t g = A.group_shift;
-            const int32_t side_shift = 3 - (g >> 1);                // block side = 8, 4, 2, 1 pixels
-            const int32_t blocks_shift = g;                         // blocks per tile = 64 / side^2 = 2^g
-            const int32_t block = wv & ((1 << blocks_shift) - 1);
-            const int32_t sgroup = wv >> blocks_shift;
-            const int32_t in_block = lane & ((64 >> g) - 1);
-            const int32_t bx = block & ((8 >> side_shift) - 1), by = block >> (3 - side_shift);
-            const int32_t px = (bx << side_shift) + (in_block & ((1 << side_shift) - 1));
-            const int32_t py = (by << side_shift) + (in_block >> side_shift);
-            const int32_t pix = py * 8 + px;
-            const int32_t soff = (sgroup << g) + (lane >> (6 - g));
-            const int32_t tile = A.tile_ids[tpos];
-            const int32_t col = (tile % A.tiles_x) * 8 + (pix & 7);
-            const int32_t row = (tile / A.tiles_x) * 8 + (pix >> 3);
+            const TileSlot ts = tile_slot(A, k);
+            const int32_t col = ts.col, row = ts.row, soff = ts.soff;
             if (col >= A.cam.width || row >= A.cam.height) {
                 live = false;
             } else {
                 pixel = row * A.cam.width + col;
                 sample = A.sample_begin + soff;
-                acc_row = tpos * 64 + pix;
-                ko = (tpos * A.n_samples + soff) * 64 + pix;     // (tile, sample, pixel in tile) order
+                acc_row = ts.acc_row;
+                ko = ts.ko;
                 // camera.py:78 (+ :246): one pattern choice per pixel, plus an independent
                 // disk pattern for a thin lens; camera.py:90-93: the view-plane point.
                 const rtamd_sampler sm = S.samplers[A.cam.sampler];
@@ -181,6 +194,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         dr.sample = (uint32_t)sample;
         dr.counter = 0;
         Primary first;
+        first.object = A.out.hit_object; first.prim = A.out.hit_prim; first.t = A.out.hit_t; first.row = ko;
         // the wave's kd traversal stack (one wave per workgroup)
         __shared__ double stack_t[TREES ? LDS_STACK * 64 : 1];
         __shared__ int32_t stack_node[TREES ? LDS_STACK * 64 : 1];
@@ -194,9 +208,6 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
             if (A.out.rgb) { A.out.rgb[3 * ko] = c.x; A.out.rgb[3 * ko + 1] = c.y; A.out.rgb[3 * ko + 2] = c.z; }
             if (A.out.rgb8) { A.out.rgb8[3 * ko] = r8; A.out.rgb8[3 * ko + 1] = g8; A.out.rgb8[3 * ko + 2] = b8; }
-            if (A.out.hit_object) A.out.hit_object[ko] = first.object;
-            if (A.out.hit_prim) A.out.hit_prim[ko] = first.prim;
-            if (A.out.hit_t) A.out.hit_t[ko] = first.t;
             if (A.out.n_rays) { A.out.n_rays[2 * ko] = (int32_t)work.closest; A.out.n_rays[2 * ko + 1] = (int32_t)work.shadow; }
             if (MODE == MODE_TILES) {
                 if (A.sum_rgb8) {
