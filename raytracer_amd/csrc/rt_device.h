@@ -94,7 +94,7 @@ __device__ __forceinline__ void draw_square(const rtamd_scene_desc& S, int sid, 
 
 // ---------------------------------------------------------------- work counters
 #ifdef RT_PHASE_TIMERS
-__device__ unsigned long long g_phase_cycles[32];
+__device__ unsigned long long g_phase_cycles[48];
 // coarse marks along a wave's life (profiling builds): cycles since the previous mark go to `slot`
 struct WaveMarks {
     long long mark_t = 0;
@@ -1296,7 +1296,7 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
         sr.o = h.p;
         sr.d = v3(0, 0, 1);
         if (lit) sr.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
-        w.mark(30);
+        w.mark(33);     // from the closest hit to the ambient-occlusion ray
         if (occluded_wave<COUNT, TREES>(S, stk, lit, sr, false, 0.0, w)) amb = ld3(S.ambient.occluded);
         w.mark(18);     // ambient occlusion query, kd query included
     }
@@ -1340,7 +1340,7 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
             if (lt.kind == RTAMD_POINT) limit = norm(sr.o - ld3(lt.position));                    // light.py:32
             else if (lt.kind == RTAMD_AREA) limit = dot(sample_point - sr.o, sr.d);               // light.py:125
             const bool bounded = lt.kind == RTAMD_POINT || lt.kind == RTAMD_AREA;
-            w.mark(30);
+            w.mark(34);     // light sample and shadow ray set-up
             if (__ballot(facing)) in_shadow = occluded_wave<COUNT, TREES>(S, stk, facing, sr, bounded, limit, w);
             w.mark(19);     // light shadow query, kd query included
         }
@@ -1449,7 +1449,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
         }
         Hit h;
         h.p = v3(0, 0, 0); h.n = v3(0, 0, 1); h.material = 0;
-        w.mark(30);     // ray generation / previous bounce
+        w.mark(32);     // ray generation / previous bounce
         const bool hit = closest_hit_wave<COUNT, TREES>(S, stk, alive, primary, ray, w, h);
         w.mark(31);     // closest hit, kd query included
         if (alive && !hit) { L = L + W * background; alive = false; }

@@ -50,7 +50,7 @@ def main():
     World.__init__(world, viewmode="parallel", buildfunction=scene, seed=1)
     job = distributed.FrameJob(world, 0, 1)
     lib = capi.library()
-    table = (C.c_ulonglong * 32)()
+    table = (C.c_ulonglong * 48)()
     job.render()
     torch.cuda.synchronize()
     lib.rtamd_debug_phase_cycles(table, 1)
@@ -72,7 +72,9 @@ def main():
     if t[27]:
         out["packed_shadow_sharing"] = {"episodes": t[27], "rays": t[25], "distinct_leaves": t[26]}
     out["marks_inclusive"] = {"closest_hit_incl_kd": t[31] / float(total), "ambient_occlusion_incl_kd": t[18] / float(total),
-                              "light_shadow_incl_kd": t[19] / float(total), "everything_between": t[30] / float(total)}
+                              "light_shadow_incl_kd": t[19] / float(total), "ray_generation": t[32] / float(total),
+                              "hit_to_ambient_ray": t[33] / float(total), "light_setup": t[34] / float(total),
+                              "shade_and_write": t[35] / float(total)}
     if t[28]:
         out["shadow_rounds"] = {"rounds": t[28], "lanes_walking_per_round": t[29] / float(t[28])}
     print(json.dumps(out, indent=1))
