@@ -276,3 +276,70 @@ def test_two_child_materials_are_checked_by_the_library(torch_gpu):
     assert numpy.array_equal(got["n_rays"], want["n_rays"])
     close, worst = common.rgb_close(got["rgb"], want["rgb"])
     assert close, worst
+
+
+def test_full_size_bench_frame_properties(torch_gpu):
+    """The benchmark's own frame (dragon, 1920x1080, 16 samples per pixel, ambient occlusion +
+    area light) at full size, through properties that need no reference run of that size:
+    the timed kernel equals the counting kernel (which walks the tree as the reference does,
+    without leaf boxes, short rounds or handed-over walks); the frame is the sum of its
+    parts, split by tiles or by sample ranges; two runs are identical; the ray counts are
+    those of the tracer (one closest-hit query per sample, at most two shadow queries); and
+    randomly chosen whole tiles equal the CPU oracle's."""
+    import bench
+    from raytracer_amd import flatten, runtime
+    from raytracer_amd.world import World
+    from oracle import oracle
+    torch = torch_gpu
+    scene, overrides = bench.WORKLOADS["dragon_1080p_16spp_ao_arealight"]
+    world = World.__new__(World)
+    world.overrides = overrides
+    World.__init__(world, viewmode="parallel", buildfunction=scene, seed=1)
+    ds = runtime.device_scene(world)
+    cam = flatten.camera_record(world)
+    assert (cam.width, cam.height) == (1920, 1080)
+    tx, ty = runtime.tile_grid(cam.width, cam.height)
+    tiles = numpy.arange(tx * ty, dtype=numpy.int32)
+    n_samples = 16
+
+    def render(tile_ids, s0, s1, into=None, **kw):
+        fb = into if into is not None else runtime.FrameBuffers(ds, tile_ids)
+        ds.render_tiles(cam, world.seed, fb.tile_ids, s0, s1, sum_rgb8=fb.sum_rgb8, **kw)
+        torch.cuda.synchronize()
+        return fb
+
+    ds.read_counters(reset=True)
+    whole = render(tiles, 0, n_samples)
+    c = ds.read_counters(reset=True)
+    assert c["samples"] == 1920 * 1080 * 16 and c["closest"] == c["samples"]
+    assert c["samples"] < c["shadow"] <= 2 * c["samples"]
+    again = render(tiles, 0, n_samples)
+    assert torch.equal(again.sum_rgb8, whole.sum_rgb8)
+    assert ds.read_counters(reset=True) == c
+    counted = render(tiles, 0, n_samples, count_work=True)
+    cc = ds.read_counters(reset=True)
+    assert torch.equal(counted.sum_rgb8, whole.sum_rgb8)
+    assert (cc["closest"], cc["shadow"]) == (c["closest"], c["shadow"]) and cc["tri_tests"] > 0
+    # by sample ranges into one accumulator
+    parts = render(tiles, 0, 4)
+    render(tiles, 4, 12, into=parts)
+    render(tiles, 12, 16, into=parts)
+    assert torch.equal(parts.sum_rgb8, whole.sum_rgb8)
+    # by tiles: the shares of three ranks, as the multi-GPU driver deals them
+    from raytracer_amd import distributed
+    img = runtime.scatter_tiles(whole.sum_rgb8.cpu().numpy(), tiles, cam.width, cam.height)
+    total = numpy.zeros_like(img)
+    for rank in range(3):
+        share = distributed.tiles_of_rank(cam.width, cam.height, rank, 3)
+        fb = render(share, 0, n_samples)
+        total += runtime.scatter_tiles(fb.sum_rgb8.cpu().numpy(), share, cam.width, cam.height)
+    assert numpy.array_equal(total, img)
+    # random whole tiles against the oracle
+    pick = numpy.sort(numpy.random.RandomState(3).choice(tx * ty, size=96, replace=False)).astype(numpy.int32)
+    want, _, _ = oracle.OracleScene(ds.flat).render_tiles(cam, world.seed, pick, 0, n_samples, threads=8)
+    got = runtime.scatter_tiles(whole.sum_rgb8.cpu().numpy(), tiles, cam.width, cam.height)
+    want_img = runtime.scatter_tiles(want, pick, cam.width, cam.height)
+    mask = runtime.scatter_tiles(numpy.ones_like(want), pick, cam.width, cam.height) > 0
+    d = numpy.abs(got[mask] - want_img[mask])
+    # a sample's int(c*255) may differ by one where c*255 sits within rounding of an integer
+    assert d.max() <= n_samples and (d > 0).mean() < 0.02
