@@ -504,7 +504,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     double out_t = 0;
     bool steal_ok = STEAL && walking && (t_exit * (1.0 + 1e-9) + 1e-9 < limit);
     PhaseClock clk;
-    clk.start(SHADOW ? 8 : 0);
+    clk.start(SHADOW ? (limit_in > T_INF ? 36 : 8) : 0);     // shadow queries without a limit (ambient occlusion) apart
     clk.count(PH_QUERIES);
 
     while (__ballot(walking)) {
