@@ -155,7 +155,7 @@ def main():
 
     traffic = None
     traffic_file = os.path.join(REPO, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(traffic_file):
+    if world_size == 1 and os.path.exists(traffic_file):     # measured for the whole-frame launch of one GPU
         with open(traffic_file) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
 
