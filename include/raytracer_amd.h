@@ -362,8 +362,9 @@ int rtamd_trace_rays(rtamd_scene *scene, uint64_t seed, int64_t n,
  * get_pixel_plane_point_pairs + render_pixels (camera.py:69-98, :236-267, :60-67) for the
  * pixels of those tiles and sample indices [sample_begin, sample_end) of each pixel's
  * pattern.  tile_ids[n_tiles] index tiles row-major over ceil(width/8) x ceil(height/8).
- * Sample k of the launch is (tile k / (64*ns), sample k / 64 % ns, pixel-in-tile k % 64),
- * pixel-in-tile = 8*dy + dx; results for pixels outside the image are not written.
+ * Row k of the per-sample outputs is (tile k / (64*ns), sample k / 64 % ns, pixel-in-tile
+ * k % 64), pixel-in-tile = 8*dy + dx, however the kernel groups samples into waves; rows of
+ * pixels outside the image are not written.
  *   per_sample: optional per-sample outputs in that order (may be NULL)
  *   sum_rgb8[n_tiles*64][3]  int64: += int(c*255) per sample (numerator of parallel mode's
  *                             running mean, main.py:99-103), row = 64*position of the tile
