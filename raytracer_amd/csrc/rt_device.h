@@ -449,11 +449,18 @@ __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& 
 
 // One kd-tree query per active lane, all 64 lanes inside.
 //
-// Each lane walks the tree front to back exactly as KDTree.iterate_nodes does
-// (kdtree.py:133-155) with a private stack.  When lanes arrive at leaves:
-//   * a small leaf is scanned by its own lane;
-//   * a big leaf is handed to the wave: its ray is broadcast and the 64 lanes test 64
-//     consecutive leaf references per step (coalesced loads of the SoA table).
+// The query runs in rounds.  In a round each lane walks the tree front to back exactly as
+// KDTree.iterate_nodes does (kdtree.py:133-155), with a stack of its own, until it stands at
+// a leaf it has to test (a leaf of up to 64 rows whose triangles' box the ray misses is
+// passed by); then the leaves are tested:
+//   * rays of a tile that have not bounced yet (`coherent`) reach the same leaves, so each
+//     lane scans its own leaf from the row-major table, big leaves through their boxes;
+//   * otherwise the wave tests the leaves together with coalesced loads of the
+//     struct-of-arrays table: leaves of up to 16 / 32 rows four / two rays per step,
+//     bigger leaves 64 rows per step, only the 64-row chunks a ray's line can touch, and
+//     shadow rays that stand in the same leaf share the load of a chunk.
+// Shadow queries of non-counting launches keep their rounds short and hand parts of long
+// walks to lanes that have their answer already (see below).
 // SHADOW = false is KDTree.hit (kdtree.py:166-174): every item of the leaf is tested, the
 // strict minimum t wins, ties go to the earlier item, and the walk ends at the first leaf
 // with a hit.  SHADOW = true is KDTree.shadow_hit (kdtree.py:157-164): the first item in
