@@ -343,3 +343,57 @@ def test_full_size_bench_frame_properties(torch_gpu):
     d = numpy.abs(got[mask] - want_img[mask])
     # a sample's int(c*255) may differ by one where c*255 sits within rounding of an integer
     assert d.max() <= n_samples and (d > 0).mean() < 0.02
+
+
+def test_kd_shortcuts_from_other_viewpoints(torch_gpu):
+    """The dragon scene from five other viewpoints (around it, above it, inside its bounding
+    box), other seeds: the timed kernel - leaf boxes, short rounds, walks handed between lanes,
+    shared chunk loads - gives the counting kernel's frame exactly, and the counting kernel
+    gives the oracle's primary hits, ray counts and work counters."""
+    import bench
+    from raytracer_amd import flatten, runtime
+    from raytracer_amd.world import World
+    from oracle import oracle
+    torch = torch_gpu
+    scene, _ = bench.WORKLOADS["dragon_1080p_16spp_ao_arealight"]
+    world = World.__new__(World)
+    world.overrides = dict(resolution=(240, 136), sample_dim=2)
+    World.__init__(world, viewmode="parallel", buildfunction=scene, seed=1)
+    ds = runtime.device_scene(world)
+    osc = oracle.OracleScene(ds.flat)
+    eye0 = numpy.array(world.camera.eye, dtype=float)
+    look0 = numpy.array(world.camera.lookat, dtype=float)
+    dist = numpy.linalg.norm(eye0 - look0)
+    views = [
+        (look0 + numpy.array([dist, 0.3 * dist, 0.0]), look0),
+        (look0 + numpy.array([-0.7 * dist, 0.2 * dist, -0.7 * dist]), look0),
+        (look0 + numpy.array([0.05 * dist, 1.2 * dist, 0.05 * dist]), look0),
+        (look0 + 0.25 * (eye0 - look0), look0),
+        (look0 + numpy.array([0.0, 0.02 * dist, 0.0]), look0 + numpy.array([dist, 0.1 * dist, 0.3 * dist])),
+    ]
+    tx, ty = runtime.tile_grid(240, 136)
+    tiles = numpy.arange(tx * ty, dtype=numpy.int32)
+    for i, (eye, lookat) in enumerate(views):
+        world.camera.eye = numpy.array(eye)
+        world.camera.lookat = numpy.array(lookat)
+        world.camera.compute_uwv()
+        cam = flatten.camera_record(world)
+        seed = 100 + i
+        n = len(tiles) * 64 * 4
+        timed = runtime.FrameBuffers(ds, tiles)
+        ds.render_tiles(cam, seed, timed.tile_ids, 0, 4, sum_rgb8=timed.sum_rgb8, sum_sq=timed.sum_sq)
+        counted = runtime.FrameBuffers(ds, tiles)
+        per = ds.sample_buffers(n, want=("hit_object", "hit_prim", "n_rays"))
+        ds.read_counters(reset=True)
+        ds.render_tiles(cam, seed, counted.tile_ids, 0, 4, sum_rgb8=counted.sum_rgb8, sum_sq=counted.sum_sq,
+                        per_sample=per, count_work=True)
+        torch.cuda.synchronize()
+        work = ds.read_counters(reset=True)
+        assert torch.equal(timed.sum_rgb8, counted.sum_rgb8), "view %d" % i
+        assert torch.equal(timed.sum_sq, counted.sum_sq), "view %d" % i
+        _, _, want = osc.render_tiles(cam, seed, tiles, 0, 4, per_sample_want=("hit_object", "hit_prim", "n_rays"),
+                                      threads=8)
+        assert work == osc.read_counters(reset=True), "view %d" % i
+        for key in ("hit_object", "hit_prim", "n_rays"):
+            assert numpy.array_equal(per[0][key].cpu().numpy(), want[key]), "view %d: %s" % (i, key)
+        assert work["shadow"] > 0 and work["tri_tests"] > 0
