@@ -397,3 +397,56 @@ def test_kd_shortcuts_from_other_viewpoints(torch_gpu):
         for key in ("hit_object", "hit_prim", "n_rays"):
             assert numpy.array_equal(per[0][key].cpu().numpy(), want[key]), "view %d: %s" % (i, key)
         assert work["shadow"] > 0 and work["tri_tests"] > 0
+
+
+@pytest.mark.parametrize("tables", ("canonical", "order_and_chunk_boxes", "no_leaf_aabb"))
+def test_optional_device_tables_may_be_absent(torch_gpu, tables):
+    """The derived tables of rtamd_scene_desc are optional.  A scene handle made without them
+    renders the same frame as the full one: with the canonical tables alone (rows in scan
+    order, every big leaf scanned in full), with only tri_order + chunk_boxes beside the
+    re-arranged rows (the wave tests chunk boxes ray by ray), and with everything but
+    leaf_aabb."""
+    import ctypes as C
+    from raytracer_amd import capi, flatten, runtime
+    torch = torch_gpu
+    world = _tiny_world("dragon_area", resolution=(96, 64), sample_dim=2, seed=4)
+    ds = runtime.device_scene(world)
+    lib = capi.library()
+    cam = flatten.camera_record(world)
+    tx, ty = runtime.tile_grid(96, 64)
+    tiles = numpy.arange(tx * ty, dtype=numpy.int32)
+    full = runtime.FrameBuffers(ds, tiles)
+    ds.render_tiles(cam, world.seed, full.tile_ids, 0, 4, sum_rgb8=full.sum_rgb8)
+
+    keep = []
+    if tables == "canonical":
+        def address_of(name, arr):
+            t = torch.from_numpy(numpy.ascontiguousarray(arr).view(numpy.uint8).reshape(-1).copy())
+            t = (t if t.numel() else torch.zeros(16, dtype=torch.uint8)).to(ds.device)
+            keep.append(t)
+            return t.data_ptr()
+        desc = ds.flat.desc(address_of)
+        desc.kd_triples = ds.tensors["kd_triples"].data_ptr()   # node records do not depend on the row order...
+        # ...except a leaf's chunk index, which is only read when chunk_boxes is given
+    else:
+        desc = ds.flat.desc(lambda name, arr: ds.tensors[name].data_ptr())
+        desc.kd_triples = ds.tensors["kd_triples"].data_ptr()
+        desc.tri_order = ds.tensors["tri_order"].data_ptr()
+        desc.chunk_boxes = ds.tensors["chunk_boxes"].data_ptr()
+        desc.n_chunks = ds.tensors["chunk_boxes"].numel() // 48
+        if tables == "no_leaf_aabb":
+            desc.tri_rows = ds.tensors["tri_rows"].data_ptr()
+            desc.leaf_boxes = ds.tensors["leaf_boxes"].data_ptr()
+            desc.chunk_tree = ds.tensors["chunk_tree"].data_ptr()
+    handle = C.c_void_p()
+    capi.check(lib.rtamd_scene_create(C.byref(desc), C.byref(handle)), lib)
+    try:
+        other = runtime.FrameBuffers(ds, tiles)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        capi.check(lib.rtamd_render_tiles(handle, C.byref(cam), world.seed, len(tiles), other.tile_ids.data_ptr(),
+                                          0, 4, None, other.sum_rgb8.data_ptr(), None, None, 0, stream), lib)
+        torch.cuda.synchronize()
+        assert torch.equal(other.sum_rgb8, full.sum_rgb8)
+        assert int(full.sum_rgb8.sum()) > 0
+    finally:
+        lib.rtamd_scene_destroy(handle)
