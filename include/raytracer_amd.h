@@ -275,19 +275,19 @@ typedef struct rtamd_scene_desc {
     int64_t n_texel_bytes;
     const rtamd_texture *textures;      /* device, NULL when n_textures == 0 */
     const uint8_t *texels;              /* device */
-    const double *chunk_tree;           /* device, optional: [n_chunks][12] = per chunk its box
-                                           (as chunk_boxes) and, for every fourth chunk of a
-                                           leaf counted from the leaf's first, the box around
-                                           that chunk and the next three of the same leaf
-                                           (zeros elsewhere): what a lane reads when it sorts
-                                           out which chunks of a leaf its own shadow ray can
-                                           touch.  NULL: the wave tests the chunk boxes of one
-                                           ray at a time */
-    const double *leaf_aabb;            /* device, optional: [n_kd_nodes][6] = for a leaf of at most
-                                           64 rows the box around its triangles, lo.xyz hi.xyz
-                                           (conservative); zeros for other nodes.  A ray that
-                                           crosses the leaf's cell but misses this box skips
-                                           the leaf */
+    const float *chunk_tree;            /* device, optional: [n_chunks][12] floats = per chunk its box
+                                           (as chunk_boxes, rounded outward to single precision:
+                                           it only culls) and, for every fourth chunk of a leaf
+                                           counted from the leaf's first, the box around that
+                                           chunk and the next three of the same leaf (zeros
+                                           elsewhere): what a lane reads when it sorts out which
+                                           chunks of a leaf its own shadow ray can touch.  NULL:
+                                           the wave tests the chunk boxes of one ray at a time */
+    const float *leaf_aabb;             /* device, optional: [n_kd_nodes][8] floats = for a leaf of at
+                                           most 64 rows the box around its triangles, lo.xyz
+                                           hi.xyz and two unused (conservative, rounded
+                                           outward); zeros for other nodes.  A ray that crosses
+                                           the leaf's cell but misses this box skips the leaf */
 } rtamd_scene_desc;
 
 /* Camera and view plane (camera.py:12-33, :142-146, :222-225; tracer.py:91-95). */

@@ -403,17 +403,30 @@ __device__ __forceinline__ bool box_touch(const double* bx, const Ray& q, V3 inv
     return !(tn > tf) && !(tf < 0.0);
 }
 
-// The same test reporting the exit distance.
-__device__ __forceinline__ bool box_touch_far(const double* bx, const Ray& q, V3 inv, double& tf) {
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const d2* p = reinterpret_cast<const d2*>(bx);
-    const d2 a = p[0], b = p[1], c = p[2];
-    const double x0 = (a.x - q.o.x) * inv.x, x1 = (b.y - q.o.x) * inv.x;
-    const double y0 = (a.y - q.o.y) * inv.y, y1 = (c.x - q.o.y) * inv.y;
-    const double z0 = (b.x - q.o.z) * inv.z, z1 = (c.y - q.o.z) * inv.z;
-    const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+// The same tests on a box given as six floats lo.xyz, hi.xyz inside two 16-byte quads
+// q0 = f[0..3], q1 = f[4..7] starting at float `at` (0 or 2) of q0: boxes that only cull are
+// kept in single precision, rounded outward, which halves what a lane loads for them.
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool box_touch6(double lx, double ly, double lz, double hx, double hy, double hz,
+                                           const Ray& q, V3 inv, double& tn, double& tf) {
+    const double x0 = (lx - q.o.x) * inv.x, x1 = (hx - q.o.x) * inv.x;
+    const double y0 = (ly - q.o.y) * inv.y, y1 = (hy - q.o.y) * inv.y;
+    const double z0 = (lz - q.o.z) * inv.z, z1 = (hz - q.o.z) * inv.z;
+    tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
     tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
     return !(tn > tf) && !(tf < 0.0);
+}
+// box in floats 0..5 of the 32 bytes at p
+__device__ __forceinline__ bool box_touch_f(const float* p, const Ray& q, V3 inv, double& tn, double& tf) {
+    const f4* v = reinterpret_cast<const f4*>(p);
+    const f4 a = v[0], b = v[1];
+    return box_touch6(a.x, a.y, a.z, a.w, b.x, b.y, q, inv, tn, tf);
+}
+// box in floats 6..11 of the 48 bytes at p (the group box of a chunk_tree row)
+__device__ __forceinline__ bool box_touch_f_second(const float* p, const Ray& q, V3 inv, double& tn, double& tf) {
+    const f4* v = reinterpret_cast<const f4*>(p);
+    const f4 b = v[1], c = v[2];
+    return box_touch6(b.z, b.w, c.x, c.y, c.z, c.w, q, inv, tn, tf);
 }
 
 // KDTree.hit's scan of one boxed leaf (kdtree.py:169-173) by the lane that owns the ray:
@@ -624,7 +637,8 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 // lane walks on at once (not when counting: the reference tests the rows)
                 if (!COUNT && use_leaf_aabb && count <= 64) {
                     double tn;
-                    if (count == 0 || !box_touch(S.leaf_aabb + (int64_t)node * 6, r, inv_d, tn)) {
+                    double tf;
+                    if (count == 0 || !box_touch_f(S.leaf_aabb + (int64_t)node * 8, r, inv_d, tn, tf)) {
                         if (sp == sb) { walking = false; first = 0; count = 0; cbase = -1; break; }
                         pop();
                         // a long run of skipped leaves ends the lane's round without a leaf, so
@@ -718,15 +732,15 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
             const V3 inv = inv_d;
             const int32_t nch = (count + 63) >> 6;
             double tn;
-            // 96-byte rows: the chunk's box, then the box around a group of four chunks (in the
-            // row of the group's first chunk); a group the ray misses is skipped whole
-            const double* rec = S.chunk_tree + (int64_t)cbase * 12;
+            // 48-byte rows of floats: the chunk's box, then the box around a group of four chunks
+            // (in the row of the group's first chunk); a group the ray misses is skipped whole
+            const float* rec = S.chunk_tree + (int64_t)cbase * 12;
+            double tf;
             for (int32_t g = 0; g < nch; g += 4) {
-                if (nch > 4 && !box_touch(rec + g * 12 + 6, r, inv, tn)) continue;
+                if (nch > 4 && !box_touch_f_second(rec + g * 12, r, inv, tn, tf)) continue;
                 const int32_t g_end = min(g + 4, nch);
                 for (int32_t j = g; j < g_end; ++j) {
-                    double tf;
-                    if (box_touch_far(rec + j * 12, r, inv, tf)) {
+                    if (box_touch_f(rec + j * 12, r, inv, tn, tf)) {
                         my_chunks |= 1ull << j;
                         if (!(tf < limit)) my_any_hit_decides = false;
                     }

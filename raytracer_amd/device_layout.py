@@ -13,8 +13,8 @@ module
     use for every tie-break and first-in-order decision, and
   * gives every 64-row chunk an axis-aligned bounding box (`chunk_boxes`, padded), so a
     wave can skip chunks a ray's line cannot touch; `chunk_tree` holds the same boxes row by
-    row together with a box around every group of four chunks of a leaf, for a lane that
-    sorts out the chunks its own ray can touch.
+    row (as floats, rounded outward) together with a box around every group of four chunks
+    of a leaf, for a lane that sorts out the chunks its own ray can touch.
 
 The degenerate leaves of the reference's build (hundreds to 1340 triangles, a few per
 mesh, visited by most rays) are where almost all triangle tests are spent; skipping
@@ -35,6 +35,14 @@ PAD = 1.0e-9
 
 def _padded(lo, hi):
     return lo - PAD * (1.0 + numpy.abs(lo)), hi + PAD * (1.0 + numpy.abs(hi))
+
+
+def _boxes_f32(lo, hi):
+    """(n, 3) double boxes as float32 that still enclose them (rounded outward)."""
+    lo32, hi32 = lo.astype(numpy.float32), hi.astype(numpy.float32)
+    lo32 = numpy.where(lo32.astype(numpy.float64) > lo, numpy.nextafter(lo32, numpy.float32(-numpy.inf)), lo32)
+    hi32 = numpy.where(hi32.astype(numpy.float64) < hi, numpy.nextafter(hi32, numpy.float32(numpy.inf)), hi32)
+    return lo32.astype(numpy.float32), hi32.astype(numpy.float32)
 
 
 def _morton_order(centroids):
@@ -111,7 +119,14 @@ def device_arrays(flat):
     a["tri_rows"] = rows.ravel()
     a["chunk_boxes"] = chunk_boxes.ravel()
     a["leaf_boxes"] = numpy.concatenate(leaf_boxes).ravel() if leaf_boxes else numpy.zeros(0)
-    a["chunk_tree"] = chunk_tree.ravel()
+    # culling only: single precision, rounded outward, is enough and halves what a lane loads
+    ct32 = numpy.zeros((n_chunks, 12), dtype=numpy.float32)
+    if n_chunks:
+        ct32[:, 0:3], ct32[:, 3:6] = _boxes_f32(chunk_tree[:, 0:3], chunk_tree[:, 3:6])
+        has_group = chunk_tree[:, 6:12].any(axis=1)
+        glo, ghi = _boxes_f32(chunk_tree[has_group, 6:9], chunk_tree[has_group, 9:12])
+        ct32[has_group, 6:9], ct32[has_group, 9:12] = glo, ghi
+    a["chunk_tree"] = ct32.ravel()
     # box around the triangles of every leaf of at most CHUNK rows (bigger leaves have chunk boxes)
     leaf_aabb = numpy.zeros((len(nodes), 6))
     small = leaves[(counts > 0) & (counts <= CHUNK)]
@@ -125,7 +140,10 @@ def device_arrays(flat):
         lo = numpy.minimum.reduceat(numpy.minimum(numpy.minimum(v0, v1), v2), seg, axis=1).T
         hi = numpy.maximum.reduceat(numpy.maximum(numpy.maximum(v0, v1), v2), seg, axis=1).T
         leaf_aabb[small, 0:3], leaf_aabb[small, 3:6] = _padded(lo, hi)
-    a["leaf_aabb"] = leaf_aabb.ravel()
+    la32 = numpy.zeros((len(nodes), 8), dtype=numpy.float32)
+    if len(small):
+        la32[small, 0:3], la32[small, 3:6] = _boxes_f32(leaf_aabb[small, 0:3], leaf_aabb[small, 3:6])
+    a["leaf_aabb"] = la32.ravel()
     a["kd_nodes"] = nodes.view(numpy.uint8)
     # node, left child, right child side by side: two levels of the walk per load
     triples = numpy.zeros((len(nodes), 4), dtype=nodes.dtype)

@@ -124,14 +124,17 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
     nodes = dev["kd_nodes"].view([("split", "<f8"), ("a", "<i4"), ("b", "<i4")])
     boxes = dev["chunk_boxes"].reshape(6, n_chunks)
     leaf_boxes = dev["leaf_boxes"].reshape(n_chunks, 9, 6)
-    chunk_tree = dev["chunk_tree"].reshape(n_chunks, 12)
-    assert numpy.array_equal(chunk_tree[:, :6].T, boxes)
+    chunk_tree = dev["chunk_tree"].reshape(n_chunks, 12).astype(numpy.float64)
+    assert dev["chunk_tree"].dtype == numpy.float32 and dev["leaf_aabb"].dtype == numpy.float32
+    # single-precision copies enclose the double boxes and stay close to them
+    assert (chunk_tree[:, 0:3].T <= boxes[0:3]).all() and (chunk_tree[:, 3:6].T >= boxes[3:6]).all()
+    assert numpy.allclose(chunk_tree[:, :6].T, boxes, rtol=2e-7, atol=1e-30)
     rows_aos = dev["tri_rows"].reshape(n, 10)
     assert numpy.array_equal(rows_aos[:, :9], geom.T)
     meta = numpy.ascontiguousarray(rows_aos[:, 9]).view(numpy.int32).reshape(n, 2)
     assert numpy.array_equal(meta[:, 0], dev["tri_prim"]) and numpy.array_equal(meta[:, 1], order)
     seen = 0
-    leaf_aabb = dev["leaf_aabb"].reshape(len(nodes), 6)
+    leaf_aabb = dev["leaf_aabb"].reshape(len(nodes), 8).astype(numpy.float64)[:, :6]
     assert not leaf_aabb[(nodes["b"] & 3) != 3].any()
     for index in numpy.nonzero((nodes["b"] & 3) == 3)[0]:
         nd = nodes[index]
