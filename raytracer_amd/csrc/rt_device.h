@@ -1439,13 +1439,17 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(pow(b.x, e), pow(
 // depth first in the reference's order - reflected subtree, then the refracted one - with
 // the waiting siblings in a per-lane list (one per level, RTAMD_MAX_BRANCH_LEVELS), so the
 // in-trace draw counter advances exactly as in the recursive formulation.
-template <bool COUNT, bool EXT, bool TREES>
+// AREA_ONLY: the scene runs under the AreaLightTracer (tracer.py:65-71), which never bounces:
+// the compiler then drops the bounce loop and the ray and weight it would carry through the
+// shadow queries.
+template <bool COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
 __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, const Primary& first) {
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
-    const bool shade_kind = S.tracer_kind == RTAMD_TRACER_SHADE || S.tracer_kind == RTAMD_TRACER_WHITTED;
+    const int tracer_kind = AREA_ONLY ? (int)RTAMD_TRACER_AREA : S.tracer_kind;
+    const bool shade_kind = tracer_kind == RTAMD_TRACER_SHADE || tracer_kind == RTAMD_TRACER_WHITTED;
     const V3 background = shade_kind ? ld3(S.background) : v3(0, 0, 0);
-    const bool area = S.tracer_kind == RTAMD_TRACER_AREA;
+    const bool area = tracer_kind == RTAMD_TRACER_AREA;
     const bool sample_lane = alive;
     if (sample_lane) first.put(-1, -1, 0.0);
     bool primary = true;
@@ -1489,7 +1493,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
             alive = false;
         }
 
-        if (S.tracer_kind == RTAMD_TRACER_PATH) {
+        if (tracer_kind == RTAMD_TRACER_PATH) {
             if (alive) {
                 // Lambertian.sample_f (material.py:41-53) then Matte.path_shade (:283-289)
                 V3 v = cross(v3(0.0034, 1, 0.0071), h.n);

@@ -117,7 +117,7 @@ __device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point,
 // do not pay for.
 // TREES = false instantiations serve scenes without a kd-tree (analytic primitives only):
 // no traversal code, no LDS stack, and the registers go to the shading loop.
-template <int MODE, bool COUNT, bool EXT, bool TREES>
+template <int MODE, bool COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
 __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
     // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         stk.node = stack_node;
         stk.t = stack_t;
         stk.slot = stack_slot;
-        const V3 c = trace_wave<COUNT, EXT, TREES>(S, stk, live, ray, A.depth0, dr, work, first);
+        const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, live, ray, A.depth0, dr, work, first);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
             if (A.out.rgb) { A.out.rgb[3 * ko] = c.x; A.out.rgb[3 * ko + 1] = c.y; A.out.rgb[3 * ko + 2] = c.z; }
@@ -284,6 +284,10 @@ int launch(const rtamd_scene_desc& S, bool extended, LaunchArgs& A, uint32_t fla
         else hipLaunchKernelGGL((trace_kernel<MODE, false, true, true>), grid, block, 0, st, S, A);
     } else if (trees) {
         if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false, true>), grid, block, 0, st, S, A);
+#ifndef RT_NO_AREA_ONLY
+        else if (MODE == MODE_TILES && S.tracer_kind == RTAMD_TRACER_AREA)
+            hipLaunchKernelGGL((trace_kernel<MODE, false, false, true, true>), grid, block, 0, st, S, A);
+#endif
         else hipLaunchKernelGGL((trace_kernel<MODE, false, false, true>), grid, block, 0, st, S, A);
     } else {
         if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false, false>), grid, block, 0, st, S, A);
