@@ -1352,6 +1352,31 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
         }
         const double ndotwi = dot(h.n, wi);
         const bool facing = lit && ndotwi > 0 && !(textured && !(dot(h.n, wo) > 0.));
+        // the light's contribution is worked out before its shadow query, so that only the
+        // finished term - not the vectors it is made of - waits in registers through the query
+        const bool wanted = facing && gate;
+        V3 term = v3(0, 0, 0);
+        if (wanted) {
+            V3 f = ld3(m.diffuse);
+            if (textured) f = (f * tex) / PI;                                                    // material.py:27-28
+            if (phong) f = f + phong_lobe(ld3(m.specular), m.exp, h.n, wo, wi);
+            V3 Ll = ld3(lt.radiance);
+            if (lt.kind == RTAMD_POINT && lt.attenuation != 0)                                    // light.py:39-44
+                Ll = Ll * pow(norm(h.p - ld3(lt.position)) / lt.radius, -lt.attenuation);
+            if (lt.kind == RTAMD_AREA && !(dot(ld3(lt.normal), wi) < 0.)) Ll = v3(0, 0, 0);        // light.py:110-114
+            term = (f * Ll) * ndotwi;
+            if (area) {
+                double G = 1.0, pdf = 1.0;                                                        // light.py:149-150, :177-178
+                if (lt.kind == RTAMD_AREA) {                                                      // light.py:132-140
+                    const double ndotd = -dot(ld3(lt.normal), wi);
+                    const V3 dv = sample_point - h.p;
+                    const double d2 = (((0 + dv.x * dv.x) + dv.y * dv.y) + dv.z * dv.z) / (lt.radius * lt.radius);
+                    G = ndotd / pymax(1., d2);
+                    pdf = lt.pdf;
+                }
+                term = (term * G) / pdf;
+            }
+        }
         bool in_shadow = false;
         if (lt.cast_shadow) {
             Ray sr;
@@ -1361,31 +1386,11 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
             if (lt.kind == RTAMD_POINT) limit = norm(sr.o - ld3(lt.position));                    // light.py:32
             else if (lt.kind == RTAMD_AREA) limit = dot(sample_point - sr.o, sr.d);               // light.py:125
             const bool bounded = lt.kind == RTAMD_POINT || lt.kind == RTAMD_AREA;
-            w.mark(34);     // light sample and shadow ray set-up
+            w.mark(34);     // light sample, its term and shadow ray set-up
             if (__ballot(facing)) in_shadow = occluded_wave<COUNT, TREES>(S, stk, facing, sr, bounded, limit, w);
             w.mark(19);     // light shadow query, kd query included
         }
-        if (!facing || in_shadow || !gate) continue;
-        V3 f = ld3(m.diffuse);
-        if (textured) f = (f * tex) / PI;                                                        // material.py:27-28
-        if (phong) f = f + phong_lobe(ld3(m.specular), m.exp, h.n, wo, wi);
-        V3 Ll = ld3(lt.radiance);
-        if (lt.kind == RTAMD_POINT && lt.attenuation != 0)                                        // light.py:39-44
-            Ll = Ll * pow(norm(h.p - ld3(lt.position)) / lt.radius, -lt.attenuation);
-        if (lt.kind == RTAMD_AREA && !(dot(ld3(lt.normal), wi) < 0.)) Ll = v3(0, 0, 0);            // light.py:110-114
-        V3 term = (f * Ll) * ndotwi;
-        if (area) {
-            double G = 1.0, pdf = 1.0;                                                            // light.py:149-150, :177-178
-            if (lt.kind == RTAMD_AREA) {                                                          // light.py:132-140
-                const double ndotd = -dot(ld3(lt.normal), wi);
-                const V3 dv = sample_point - h.p;
-                const double d2 = (((0 + dv.x * dv.x) + dv.y * dv.y) + dv.z * dv.z) / (lt.radius * lt.radius);
-                G = ndotd / pymax(1., d2);
-                pdf = lt.pdf;
-            }
-            term = (term * G) / pdf;
-        }
-        L = L + term;
+        if (wanted && !in_shadow) L = L + term;
     }
     return L;
 }
