@@ -194,7 +194,11 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         dr.sample = (uint32_t)sample;
         dr.counter = 0;
         Primary first;
-        first.object = A.out.hit_object; first.prim = A.out.hit_prim; first.t = A.out.hit_t; first.row = ko;
+        // (the AREA_ONLY instantiation is only launched without per-sample outputs)
+        first.object = AREA_ONLY ? nullptr : A.out.hit_object;
+        first.prim = AREA_ONLY ? nullptr : A.out.hit_prim;
+        first.t = AREA_ONLY ? nullptr : A.out.hit_t;
+        first.row = ko;
         // the wave's kd traversal stack (one wave per workgroup)
         __shared__ double stack_t[TREES ? LDS_STACK * 64 : 1];
         __shared__ int32_t stack_node[TREES ? LDS_STACK * 64 : 1];
@@ -206,9 +210,11 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, live, ray, A.depth0, dr, work, first);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
+            if (!AREA_ONLY) {
             if (A.out.rgb) { A.out.rgb[3 * ko] = c.x; A.out.rgb[3 * ko + 1] = c.y; A.out.rgb[3 * ko + 2] = c.z; }
             if (A.out.rgb8) { A.out.rgb8[3 * ko] = r8; A.out.rgb8[3 * ko + 1] = g8; A.out.rgb8[3 * ko + 2] = b8; }
             if (A.out.n_rays) { A.out.n_rays[2 * ko] = (int32_t)work.closest; A.out.n_rays[2 * ko + 1] = (int32_t)work.shadow; }
+            }
             if (MODE == MODE_TILES) {
                 if (A.sum_rgb8) {
                     unsigned long long* s = reinterpret_cast<unsigned long long*>(A.sum_rgb8) + 3 * acc_row;
@@ -285,7 +291,8 @@ int launch(const rtamd_scene_desc& S, bool extended, LaunchArgs& A, uint32_t fla
     } else if (trees) {
         if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false, true>), grid, block, 0, st, S, A);
 #ifndef RT_NO_AREA_ONLY
-        else if (MODE == MODE_TILES && S.tracer_kind == RTAMD_TRACER_AREA)
+        else if (MODE == MODE_TILES && S.tracer_kind == RTAMD_TRACER_AREA && !A.out.rgb && !A.out.rgb8 &&
+                 !A.out.hit_object && !A.out.hit_prim && !A.out.hit_t && !A.out.n_rays)
             hipLaunchKernelGGL((trace_kernel<MODE, false, false, true, true>), grid, block, 0, st, S, A);
 #endif
         else hipLaunchKernelGGL((trace_kernel<MODE, false, false, true>), grid, block, 0, st, S, A);
