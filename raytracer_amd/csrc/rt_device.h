@@ -1212,16 +1212,59 @@ __device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, 
 
 // light.in_shadow for every lane with `need`: any object that reports a hit [closer than
 // `limit`] (light.py:31-37 / :124-130 with a distance, :60-65 / :78-83 / :170-175 without).
-template <bool COUNT, bool TREES>
+// Shadow test of one analytic object (the shadow_hit methods of geometry.py).
+__device__ __forceinline__ bool analytic_shadow(const rtamd_object& ob, const Ray& r, double& t) {
+    const double* p = ob.p;
+    switch (ob.kind) {
+    case RTAMD_SPHERE: { V3 temp; return sphere_t(p, r, temp, t); }
+    case RTAMD_PLANE:
+    case RTAMD_CHECKER_PLANE: return plane_t(ld3(p), ld3(p + 3), r, t);
+    case RTAMD_RECTANGLE: return rectangle_t(p, r, t);
+    case RTAMD_BOX: return box_shadow(p, r, t);
+    case RTAMD_TRIANGLE: {
+        const double g[9] = {p[0], p[1], p[2], p[3] - p[0], p[4] - p[1], p[5] - p[2],
+                             p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+        double a, b;
+        return tri_solve(g, r, a, b, t);
+    }
+    default: return false;
+    }
+}
+
+template <bool COUNT, bool TREES, bool ONE_TREE = false>
 __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, bool need, const Ray& ray,
                               bool use_limit, double limit, Work<COUNT>& w) {
     if (need) w.shadow++;
     bool occ = false;
+    if (ONE_TREE) {
+        // The scene holds exactly one kd-tree (and the launch does not count the reference's
+        // work, whose object order matters): the analytic objects are asked first and the
+        // tree last - "any object" does not depend on the order - so that nothing of the
+        // caller's ray has to outlive the tree's query.
+        int tree_object = 0;
+        for (int i = 0; i < S.n_objects; ++i) {
+            const rtamd_object& ob = S.objects[i];
+            if (ob.kind == RTAMD_KDTREE) { tree_object = i; continue; }
+            if (!(need && !occ && ob.cast_shadow)) continue;
+            const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+            double t = 0;
+            if (analytic_shadow(ob, r, t) && (!use_limit || t < limit)) occ = true;
+        }
+        const rtamd_object& ob = S.objects[tree_object];
+        const bool q = need && !occ;
+        if (__ballot(q)) {
+            const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+            TriHit th;
+            bool f;
+            kd_query_wave<COUNT, true>(S, S.trees[ob.tree], q, r, use_limit ? limit : T_INF * 4.0, false, stk, w, f, th);
+            if (q && f && (!use_limit || th.t < limit)) occ = true;
+        }
+        return occ;
+    }
     for (int i = 0; i < S.n_objects; ++i) {
         const rtamd_object& ob = S.objects[i];
         const bool q = need && !occ;
         const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
-        const double* p = ob.p;
         double t = 0;
         bool hit = false;
         if (TREES && ob.kind == RTAMD_KDTREE) {
@@ -1234,20 +1277,7 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
             }
         } else if (q && ob.cast_shadow) {
             w.analytic();
-            switch (ob.kind) {
-            case RTAMD_SPHERE: { V3 temp; hit = sphere_t(p, r, temp, t); } break;
-            case RTAMD_PLANE:
-            case RTAMD_CHECKER_PLANE: hit = plane_t(ld3(p), ld3(p + 3), r, t); break;
-            case RTAMD_RECTANGLE: hit = rectangle_t(p, r, t); break;
-            case RTAMD_BOX: hit = box_shadow(p, r, t); break;
-            case RTAMD_TRIANGLE: {
-                const double g[9] = {p[0], p[1], p[2], p[3] - p[0], p[4] - p[1], p[5] - p[2],
-                                     p[6] - p[0], p[7] - p[1], p[8] - p[2]};
-                double a, b;
-                hit = tri_solve(g, r, a, b, t);
-            } break;
-            default: break;
-            }
+            hit = analytic_shadow(ob, r, t);
         }
         if (q && hit && (!use_limit || t < limit)) occ = true;
     }
@@ -1307,7 +1337,7 @@ __device__ __forceinline__ V3 texture_color(const rtamd_scene_desc& S, int tex, 
 // visited in list order by the whole wave so that the shadow queries stay wave-wide.
 // EXT: `tex` is the texture colour of an SV_Matte hit (material.py:311-326), which scales
 // ka and kd and adds the viewer-side test of :319.
-template <bool COUNT, bool EXT, bool TREES>
+template <bool COUNT, bool EXT, bool TREES, bool ONE_TREE = false>
 __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, bool lit, const rtamd_material& m,
                                 const Hit& h, V3 wo, bool area, V3 tex, Draw& dr, Work<COUNT>& w) {
     // ambient_color.L(sr): AmbientLight (light.py:14-15) or AmbientOccluder (light.py:85-100)
@@ -1318,7 +1348,7 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
         sr.d = v3(0, 0, 1);
         if (lit) sr.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
         w.mark(33);     // from the closest hit to the ambient-occlusion ray
-        if (occluded_wave<COUNT, TREES>(S, stk, lit, sr, false, 0.0, w)) amb = ld3(S.ambient.occluded);
+        if (occluded_wave<COUNT, TREES, ONE_TREE>(S, stk, lit, sr, false, 0.0, w)) amb = ld3(S.ambient.occluded);
         w.mark(18);     // ambient occlusion query, kd query included
     }
     const bool textured = EXT && m.kind == RTAMD_SV_MATTE;
@@ -1387,7 +1417,7 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
             else if (lt.kind == RTAMD_AREA) limit = dot(sample_point - sr.o, sr.d);               // light.py:125
             const bool bounded = lt.kind == RTAMD_POINT || lt.kind == RTAMD_AREA;
             w.mark(34);     // light sample, its term and shadow ray set-up
-            if (__ballot(facing)) in_shadow = occluded_wave<COUNT, TREES>(S, stk, facing, sr, bounded, limit, w);
+            if (__ballot(facing)) in_shadow = occluded_wave<COUNT, TREES, ONE_TREE>(S, stk, facing, sr, bounded, limit, w);
             w.mark(19);     // light shadow query, kd query included
         }
         if (wanted && !in_shadow) L = L + term;
@@ -1446,7 +1476,8 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(pow(b.x, e), pow(
 // in-trace draw counter advances exactly as in the recursive formulation.
 // AREA_ONLY: the scene runs under the AreaLightTracer (tracer.py:65-71), which never bounces:
 // the compiler then drops the bounce loop and the ray and weight it would carry through the
-// shadow queries.
+// shadow queries.  The instantiation is launched for scenes with exactly one kd-tree, which
+// the shadow tests then ask last (occluded_wave<..., ONE_TREE>).
 template <bool COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
 __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, const Primary& first) {
@@ -1519,7 +1550,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
         V3 tex = v3(1, 1, 1);
         if (EXT && alive && m.kind == RTAMD_SV_MATTE)
             tex = texture_color(S, m.texture, local_hit_point(S.objects[h.object], ray, h.t));
-        const V3 Ld = direct_light_wave<COUNT, EXT, TREES>(S, stk, alive, m, h, wo, area, tex, dr, w);
+        const V3 Ld = direct_light_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, alive, m, h, wo, area, tex, dr, w);
         if (alive) L = L + W * Ld;
         if (area) { alive = false; continue; }
         if (!alive) continue;
