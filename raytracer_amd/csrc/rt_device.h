@@ -1261,8 +1261,21 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
         }
         return occ;
     }
+    if (TREES && !COUNT) {
+        // "any object" does not depend on the order: the cheap analytic objects first, so that
+        // a ray they occlude never walks a tree (a counting launch keeps the list order, which
+        // decides how much work the reference does)
+        for (int i = 0; i < S.n_objects; ++i) {
+            const rtamd_object& ob = S.objects[i];
+            if (ob.kind == RTAMD_KDTREE || !(need && !occ && ob.cast_shadow)) continue;
+            const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+            double t = 0;
+            if (analytic_shadow(ob, r, t) && (!use_limit || t < limit)) occ = true;
+        }
+    }
     for (int i = 0; i < S.n_objects; ++i) {
         const rtamd_object& ob = S.objects[i];
+        if (TREES && !COUNT && ob.kind != RTAMD_KDTREE) continue;
         const bool q = need && !occ;
         const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
         double t = 0;
@@ -1382,11 +1395,14 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
         }
         const double ndotwi = dot(h.n, wi);
         const bool facing = lit && ndotwi > 0 && !(textured && !(dot(h.n, wo) > 0.));
-        // the light's contribution is worked out before its shadow query, so that only the
-        // finished term - not the vectors it is made of - waits in registers through the query
+        // With kd-trees in the scene the light's contribution is worked out before its shadow
+        // query, so that only the finished term - not the vectors it is made of - waits in
+        // registers through the query (1.4 % on the dragon frame); scenes of analytic objects
+        // alone work it out afterwards, for the lanes that turn out lit only (7 % on the
+        // mirror hall, whose Phong lobes are costly).
         const bool wanted = facing && gate;
         V3 term = v3(0, 0, 0);
-        if (wanted) {
+        auto light_term = [&]() {
             V3 f = ld3(m.diffuse);
             if (textured) f = (f * tex) / PI;                                                    // material.py:27-28
             if (phong) f = f + phong_lobe(ld3(m.specular), m.exp, h.n, wo, wi);
@@ -1406,7 +1422,8 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
                 }
                 term = (term * G) / pdf;
             }
-        }
+        };
+        if (TREES && wanted) light_term();
         bool in_shadow = false;
         if (lt.cast_shadow) {
             Ray sr;
@@ -1420,24 +1437,15 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
             if (__ballot(facing)) in_shadow = occluded_wave<COUNT, TREES, ONE_TREE>(S, stk, facing, sr, bounded, limit, w);
             w.mark(19);     // light shadow query, kd query included
         }
-        if (wanted && !in_shadow) L = L + term;
+        if (wanted && !in_shadow) {
+            if (!TREES) light_term();
+            L = L + term;
+        }
     }
     return L;
 }
 
-// Where the primary hit of a sample is reported (object, primitive, distance): written as
-// soon as it is known, so that it does not ride in registers through the shadow queries.
-struct Primary {
-    int32_t* object;
-    int32_t* prim;
-    double* t;
-    int64_t row;
-    __device__ __forceinline__ void put(int32_t o, int32_t p, double tt) const {
-        if (object) object[row] = o;
-        if (prim) prim[row] = p;
-        if (t) t[row] = tt;
-    }
-};
+struct Primary { int32_t object, prim; double t; };
 
 // A child ray of a Transparent / Dielectric hit that waits while its sibling's subtree is
 // traced: ray, product of the weights down to it, and Dielectric's colour filter, which is
@@ -1480,14 +1488,13 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(pow(b.x, e), pow(
 // the shadow tests then ask last (occluded_wave<..., ONE_TREE>).
 template <bool COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
 __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
-                         Work<COUNT>& w, const Primary& first) {
+                         Work<COUNT>& w, Primary& first) {
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
     const int tracer_kind = AREA_ONLY ? (int)RTAMD_TRACER_AREA : S.tracer_kind;
     const bool shade_kind = tracer_kind == RTAMD_TRACER_SHADE || tracer_kind == RTAMD_TRACER_WHITTED;
     const V3 background = shade_kind ? ld3(S.background) : v3(0, 0, 0);
     const bool area = tracer_kind == RTAMD_TRACER_AREA;
-    const bool sample_lane = alive;
-    if (sample_lane) first.put(-1, -1, 0.0);
+    first.object = -1; first.prim = -1; first.t = 0;
     bool primary = true;
     PendingRay pending[EXT ? RTAMD_MAX_BRANCH_LEVELS : 1];
     int n_pending = 0;
@@ -1514,7 +1521,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
         const bool hit = closest_hit_wave<COUNT, TREES>(S, stk, alive, primary, ray, w, h);
         w.mark(31);     // closest hit, kd query included
         if (alive && !hit) { L = L + W * background; alive = false; }
-        if (alive && primary) first.put(h.object, h.prim, h.t);
+        if (alive && primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; }
         primary = false;
         if (EXT && alive && has_filter) { W = W * powv(filter, h.t); has_filter = false; }
         const rtamd_material& m = S.materials[alive ? h.material : 0];

@@ -194,11 +194,6 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         dr.sample = (uint32_t)sample;
         dr.counter = 0;
         Primary first;
-        // (the AREA_ONLY instantiation is only launched without per-sample outputs)
-        first.object = AREA_ONLY ? nullptr : A.out.hit_object;
-        first.prim = AREA_ONLY ? nullptr : A.out.hit_prim;
-        first.t = AREA_ONLY ? nullptr : A.out.hit_t;
-        first.row = ko;
         // the wave's kd traversal stack (one wave per workgroup)
         __shared__ double stack_t[TREES ? LDS_STACK * 64 : 1];
         __shared__ int32_t stack_node[TREES ? LDS_STACK * 64 : 1];
@@ -213,6 +208,9 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
             if (!AREA_ONLY) {
             if (A.out.rgb) { A.out.rgb[3 * ko] = c.x; A.out.rgb[3 * ko + 1] = c.y; A.out.rgb[3 * ko + 2] = c.z; }
             if (A.out.rgb8) { A.out.rgb8[3 * ko] = r8; A.out.rgb8[3 * ko + 1] = g8; A.out.rgb8[3 * ko + 2] = b8; }
+            if (A.out.hit_object) A.out.hit_object[ko] = first.object;
+            if (A.out.hit_prim) A.out.hit_prim[ko] = first.prim;
+            if (A.out.hit_t) A.out.hit_t[ko] = first.t;
             if (A.out.n_rays) { A.out.n_rays[2 * ko] = (int32_t)work.closest; A.out.n_rays[2 * ko + 1] = (int32_t)work.shadow; }
             }
             if (MODE == MODE_TILES) {
