@@ -1369,7 +1369,9 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
     const bool phong = m.kind != RTAMD_MATTE && !textured;
     // Matte.shade alone ignores receives_shadow (material.py:263 vs :279, :358, :374)
     const bool gate = (phong || area) ? (m.receives_shadow != 0) : true;
-    for (int li = 0; li < S.n_lights; ++li) {
+    // (the ONE_TREE instantiation is launched for scenes with a single light: the loop is then
+    // one straight pass and nothing is kept for a next light through the shadow query)
+    for (int li = 0; li < (ONE_TREE ? 1 : S.n_lights); ++li) {
         const rtamd_light& lt = S.lights[li];
         V3 wi = v3(0, 0, 1), sample_point = v3(0, 0, 0);
         if (lit) {
@@ -1485,7 +1487,7 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(pow(b.x, e), pow(
 // AREA_ONLY: the scene runs under the AreaLightTracer (tracer.py:65-71), which never bounces:
 // the compiler then drops the bounce loop and the ray and weight it would carry through the
 // shadow queries.  The instantiation is launched for scenes with exactly one kd-tree, which
-// the shadow tests then ask last (occluded_wave<..., ONE_TREE>).
+// the shadow tests then ask last (occluded_wave<..., ONE_TREE>), and exactly one light.
 template <bool COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
 __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, Primary& first) {

@@ -289,7 +289,7 @@ int launch(const rtamd_scene_desc& S, bool extended, LaunchArgs& A, uint32_t fla
     } else if (trees) {
         if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false, true>), grid, block, 0, st, S, A);
 #ifndef RT_NO_AREA_ONLY
-        else if (MODE == MODE_TILES && S.tracer_kind == RTAMD_TRACER_AREA && S.n_trees == 1 && !A.out.rgb && !A.out.rgb8 &&
+        else if (MODE == MODE_TILES && S.tracer_kind == RTAMD_TRACER_AREA && S.n_trees == 1 && S.n_lights == 1 && !A.out.rgb && !A.out.rgb8 &&
                  !A.out.hit_object && !A.out.hit_prim && !A.out.hit_t && !A.out.n_rays)
             hipLaunchKernelGGL((trace_kernel<MODE, false, false, true, true>), grid, block, 0, st, S, A);
 #endif
