@@ -1237,7 +1237,7 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
     if (need) w.shadow++;
     bool occ = false;
     if (ONE_TREE) {
-        // The scene holds exactly one kd-tree (and the launch does not count the reference's
+        // Exactly one object of the scene is a kd-tree (and the launch does not count the reference's
         // work, whose object order matters): the analytic objects are asked first and the
         // tree last - "any object" does not depend on the order - so that nothing of the
         // caller's ray has to outlive the tree's query.
@@ -1486,8 +1486,8 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(pow(b.x, e), pow(
 // in-trace draw counter advances exactly as in the recursive formulation.
 // AREA_ONLY: the scene runs under the AreaLightTracer (tracer.py:65-71), which never bounces:
 // the compiler then drops the bounce loop and the ray and weight it would carry through the
-// shadow queries.  The instantiation is launched for scenes with exactly one kd-tree, which
-// the shadow tests then ask last (occluded_wave<..., ONE_TREE>), and exactly one light.
+// shadow queries.  The instantiation is launched for scenes with exactly one kd-tree object,
+// which the shadow tests then ask last (occluded_wave<..., ONE_TREE>), and exactly one light.
 template <bool COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
 __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, Primary& first) {

@@ -267,7 +267,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 template <int MODE>
-int launch(const rtamd_scene_desc& S, bool extended, LaunchArgs& A, uint32_t flags, void* stream) {
+int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, LaunchArgs& A, uint32_t flags, void* stream) {
     const bool trees = S.n_trees > 0;
     if (A.n <= 0) return RTAMD_OK;
     A.seg_len = 0;
@@ -289,7 +289,7 @@ int launch(const rtamd_scene_desc& S, bool extended, LaunchArgs& A, uint32_t fla
     } else if (trees) {
         if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false, true>), grid, block, 0, st, S, A);
 #ifndef RT_NO_AREA_ONLY
-        else if (MODE == MODE_TILES && S.tracer_kind == RTAMD_TRACER_AREA && S.n_trees == 1 && S.n_lights == 1 && !A.out.rgb && !A.out.rgb8 &&
+        else if (MODE == MODE_TILES && S.tracer_kind == RTAMD_TRACER_AREA && tree_objects == 1 && S.n_lights == 1 && !A.out.rgb && !A.out.rgb8 &&
                  !A.out.hit_object && !A.out.hit_prim && !A.out.hit_t && !A.out.n_rays)
             hipLaunchKernelGGL((trace_kernel<MODE, false, false, true, true>), grid, block, 0, st, S, A);
 #endif
@@ -312,6 +312,7 @@ struct rtamd_scene {
     int max_tree_depth;
     bool extended;                  // two-child or textured materials: the EXT kernels run
     bool two_child;                 // Transparent / Dielectric traced recursively
+    int tree_objects;               // objects of kind RTAMD_KDTREE (one tree may stand behind several)
 };
 
 extern "C" {
@@ -376,6 +377,7 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
     s->max_tree_depth = 0;
     s->extended = false;
     s->two_child = false;
+    s->tree_objects = 0;
     s->samplers_host = new (std::nothrow) rtamd_sampler[d->n_samplers];
     if (!s->samplers_host) { delete s; return fail(RTAMD_EINVAL, "out of host memory%s"); }
     e = hipMemcpy(s->samplers_host, d->samplers, sizeof(rtamd_sampler) * d->n_samplers, hipMemcpyDeviceToHost);
@@ -463,6 +465,7 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
         e = hipMemcpy(&o, d->objects + i, sizeof(o), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the object table"); }
         const bool tree = o.kind == RTAMD_KDTREE;
+        if (tree) s->tree_objects++;
         if (o.kind < RTAMD_SPHERE || o.kind > RTAMD_KDTREE || (tree && (o.tree < 0 || o.tree >= d->n_trees)) ||
             (!tree && (o.material < 0 || o.material >= d->n_materials)) ||
             (o.kind == RTAMD_CHECKER_PLANE && (o.alt_material < 0 || o.alt_material >= d->n_materials))) {
@@ -517,7 +520,7 @@ int rtamd_render_pixels(rtamd_scene* scene, const rtamd_camera* camera, uint64_t
     A.b3 = lens_points;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_PIXELS>(scene->desc, scene->extended, A, flags, stream);
+    return launch<MODE_PIXELS>(scene->desc, scene->extended, scene->tree_objects, A, flags, stream);
 }
 
 int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t* pixel_index,
@@ -541,7 +544,7 @@ int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t
     A.depth0 = depth;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_RAYS>(scene->desc, scene->extended, A, flags, stream);
+    return launch<MODE_RAYS>(scene->desc, scene->extended, scene->tree_objects, A, flags, stream);
 }
 
 int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t seed, int64_t n_tiles,
@@ -574,7 +577,7 @@ int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t 
     A.sum_rgb8 = sum_rgb8;
     A.sum_sq = sum_sq;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_TILES>(scene->desc, scene->extended, A, flags, stream);
+    return launch<MODE_TILES>(scene->desc, scene->extended, scene->tree_objects, A, flags, stream);
 }
 
 }  // extern "C"

@@ -450,3 +450,36 @@ def test_optional_device_tables_may_be_absent(torch_gpu, tables):
         assert int(full.sum_rgb8.sum()) > 0
     finally:
         lib.rtamd_scene_destroy(handle)
+
+
+def test_two_tree_objects_under_the_area_tracer(torch_gpu):
+    """The whole-frame kernel variant for AreaLightTracer scenes asks the scene's one kd-tree
+    last in its shadow tests; with two tree objects (here the Cornell box and a shifted
+    instance of it) the general kernel must run instead.  Timed = counting = oracle."""
+    import affinetransform as transform
+    from geometry import Instance
+    from raytracer_amd import flatten, runtime
+    from oracle import oracle
+    torch = torch_gpu
+    world = _tiny_world("cornellbox_area", resolution=(64, 48), sample_dim=2, seed=6)
+    trees = [o for o in world.objects if type(o).__name__ == "KDTree"]
+    assert len(trees) == 1
+    world.objects.append(Instance(trees[0], transform.translate(0.35, 0.0, -0.4)))
+    world.invalidate()
+    ds = runtime.device_scene(world)
+    cam = flatten.camera_record(world)
+    tx, ty = runtime.tile_grid(64, 48)
+    tiles = numpy.arange(tx * ty, dtype=numpy.int32)
+    timed = runtime.FrameBuffers(ds, tiles)
+    ds.render_tiles(cam, world.seed, timed.tile_ids, 0, 4, sum_rgb8=timed.sum_rgb8)
+    counted = runtime.FrameBuffers(ds, tiles)
+    ds.read_counters(reset=True)
+    ds.render_tiles(cam, world.seed, counted.tile_ids, 0, 4, sum_rgb8=counted.sum_rgb8, count_work=True)
+    torch.cuda.synchronize()
+    work = ds.read_counters(reset=True)
+    assert torch.equal(timed.sum_rgb8, counted.sum_rgb8)
+    osc = oracle.OracleScene(ds.flat)
+    want, _, _ = osc.render_tiles(cam, world.seed, tiles, 0, 4, threads=8)
+    assert work == osc.read_counters(reset=True)
+    d = numpy.abs(counted.sum_rgb8.cpu().numpy() - want)
+    assert d.max() <= 4 and (d > 0).mean() < 0.02
