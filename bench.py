@@ -44,6 +44,22 @@ def algorithmic_bytes(c):
     return 48 * rays + 16 * c["kd_nodes"] + 72 * c["tri_tests"] + 48 * c["analytic_tests"]
 
 
+def launch_ranks(n, argv):
+    """Run this script as n ranks (one per GPU) under torch.distributed.run, as child
+    processes of a parent that has not touched the GPU; returns the launcher's exit status.
+    Replaces the worker fan-out of /root/reference/main.py:82-96."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                      # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +70,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process touches no GPU; it starts one fresh
+        # process per GPU, lets rank 0's JSON line through and leaves with their status
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import numpy
     import torch
@@ -67,6 +88,18 @@ def main():
                          % (args.gpus, world_size, args.gpus))
     # RTAMD_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks
     backend = os.environ.get("RTAMD_BENCH_BACKEND", "nccl")
+    if os.environ.get("RTAMD_BENCH_LAUNCH_ONLY"):
+        # launcher rehearsal without a GPU: rendezvous, one collective, rank 0 reports
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        seen = torch.tensor([rank + 1], dtype=torch.int64)
+        if world_size > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+            dist.all_reduce(seen)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_only": True, "n_gpus": world_size, "rank_sum": int(seen[0])}), flush=True)
+        return
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world_size > 1:

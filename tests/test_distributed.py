@@ -114,3 +114,74 @@ def test_partition_covers_every_tile_once():
             assert max(sizes) == distributed.padded_tile_count(w, h, world_size)
             if tx * ty >= 8 * world_size:
                 assert max(sizes) - min(sizes) <= max(2, tx * ty // (world_size * 20))   # balanced
+
+
+@pytest.mark.parametrize("n", (2, 4))
+def test_bench_starts_its_own_ranks(n):
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (rehearsed without
+    a GPU: rendezvous and one collective over gloo) and relays rank 0's JSON line."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["RTAMD_BENCH_LAUNCH_ONLY"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == n and line["rank_sum"] == n * (n + 1) // 2
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["RTAMD_BENCH_LAUNCH_ONLY"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--workload", "no_such_workload"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+
+
+def _nccl_worker(rank, world_size, port, out_path):
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", rank))
+    from raytracer_amd.world import World
+    from raytracer_amd import distributed
+    world = World.__new__(World)
+    world.overrides = dict(resolution=(88, 60), sample_dim=2)
+    World.__init__(world, viewmode="parallel", buildfunction="cornellbox_area", seed=3)
+    job = distributed.FrameJob(world, rank, world_size)
+    frame = job.finish(job.render())
+    if rank == 0:
+        numpy.save(out_path, frame)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl_equal_one_rank(tmp_path):
+    """Two processes, one GPU each, RCCL gather: the frame equals the single-rank frame."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    from raytracer_amd.world import World
+    from raytracer_amd import runtime
+    out = str(tmp_path / "two.npy")
+    mp.spawn(_nccl_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    world = World.__new__(World)
+    world.overrides = dict(resolution=(88, 60), sample_dim=2)
+    World.__init__(world, viewmode="parallel", buildfunction="cornellbox_area", seed=3)
+    single, _ = runtime.render_image(world, mode="parallel")
+    assert numpy.array_equal(numpy.load(out), single)
