@@ -49,6 +49,10 @@ PLAN = {
     "cornellbox":       ("parallel", None, 3000),
     "cornellbox_area":  ("parallel", None, 4000),
     "j":                ("parallel", None, 2500),
+    # the reference's own teapot worlds as shipped (smooth normals; a mirror floor; a mirror teapot)
+    "k":                ("parallel", None, 2500),
+    "mirror":           ("parallel", None, 2500),
+    "mirroralt":        ("parallel", None, 2500),
     "dragon_area":      ("parallel", dict(resolution=(480, 270), sample_dim=4), 1500),
     "features_analytic": ("parallel", None, 6000),
     "features_mesh":    ("parallel", None, 3000),

@@ -89,10 +89,28 @@ def read_mat(f, mat_sampler):
     return MaterialFactory(f, mat_sampler)
 
 
+class MeshGroups(dict):
+    """{group name: Mesh} in file order that also answers the Python 2 iteration methods the
+    reference's scene files call on it (buildfunctions/cornellbox.py:44 `iteritems`).  A
+    Python 2 dict iterates in hash order; the order here is the file's, as Python 3 gives."""
+
+    def iteritems(self):
+        return iter(self.items())
+
+    def itervalues(self):
+        return iter(self.values())
+
+    def iterkeys(self):
+        return iter(self.keys())
+
+    def has_key(self, key):
+        return key in self
+
+
 def read_mesh_complex(path, mat_sampler):
     """Grouped OBJ with an MTL library -> {group name: Mesh} in file order."""
     folder = os.path.dirname(os.path.realpath(path))
-    vertices, faces, meshes = [], [], {}
+    vertices, faces, meshes = [], [], MeshGroups()
     group = material = library = None
 
     def close():

@@ -228,7 +228,9 @@ REFERENCE_SCENES = "/root/reference/buildfunctions"
 @pytest.mark.parametrize("name,twin", [("foursphere", "foursphere"), ("glossyreflective", "glossyreflective"),
                                        ("mirrorhall", "mirrorhall"), ("i", None), ("a", None), ("b", None),
                                        ("c", None), ("d", None), ("e", None), ("f", None), ("g", None),
-                                       ("glossyreflectivehall", None), ("transparent", None)])
+                                       ("glossyreflectivehall", None), ("transparent", None),
+                                       ("cornellbox", "cornellbox"), ("k", "k"), ("mirror", "mirror"),
+                                       ("mirroralt", "mirroralt"), ("j", "j")])
 def test_reference_scene_files_load_unchanged(name, twin):
     """Drop-in check: the reference's own buildfunction files (those that are valid Python 3
     as they stand) build through this scene API and flatten; where this repo ships the same
@@ -254,9 +256,12 @@ def test_reference_scene_files_load_unchanged(name, twin):
     assert flat.nbytes() > 0
     if twin:
         # this repo's own scene file of the same name, picked by module rather than by registry
-        mine = load_scene_file(os.path.join(raytracer_amd.SCENE_DIR, twin + ".py"))
-        scene = [c for c in vars(mine).values() if isinstance(c, type)
-                 and getattr(c, "BUILD_FUNCTION_NAME", None) == twin and c.__module__ == mine.__name__]
+        import glob
+        scene = []
+        for path in sorted(glob.glob(os.path.join(raytracer_amd.SCENE_DIR, "*.py"))):
+            mine = load_scene_file(path)
+            scene += [c for c in vars(mine).values() if isinstance(c, type)
+                      and getattr(c, "BUILD_FUNCTION_NAME", None) == twin and c.__module__ == mine.__name__]
         assert len(scene) == 1
         ours = build(scene[0].build_function)
         assert sorted(flat.arrays) == sorted(ours.arrays)
