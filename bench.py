@@ -11,11 +11,23 @@ The frame is fixed, so scaling is "strong".  A ray is one closest-hit query or o
 shadow/occlusion query, counted in the kernel.  Rank 0 prints ONE JSON line.
 
 Extra fields:
-  roofline      algorithmic bytes per launch / measured kernel time against the HBM peak.
-                Algorithmic bytes follow the per-ray accounting 48 B (ray + hit record)
-                + 16 B per kd interior step + 72 B per triangle test (v0, e1, e2 in f64)
-                + 48 B per analytic object test, with the step/test counts of the
-                reference algorithm taken from a counting launch of the same frame.
+  roofline      where the tile kernel stands against three ceilings, each a fraction <= 1:
+                  hbm   bytes the L2s exchanged with memory per launch (rocprofv3 FETCH_SIZE /
+                        WRITE_SIZE, collected by this run from a profiled child process
+                        before the timed part, or - if that is not possible - taken from
+                        profiles/ when the record there was made with this library build)
+                        / kernel time / 8 TB/s: the top-level achieved / frac / traffic;
+                  l2    bytes the kernel's own loads ask for (node records, culling boxes,
+                        triangle rows, analytic objects, 48 B per ray for ray + hit record;
+                        counted by an RTAMD_COUNT_EXECUTED launch of the same frame)
+                        / kernel time / 34.5 TB/s;
+                  valu  share of SIMD cycles with a vector-ALU instruction executing, and
+                        the active lanes per instruction (SQ counters of the same child);
+                `binding` names the largest.  `reference_work` is what the reference's
+                algorithm would have moved for the same rays (per ray 48 B + 16 B per kd
+                step + 72 B per triangle test + 48 B per analytic test, counted by an
+                RTAMD_COUNT_WORK launch) and the ratio of its triangle tests to the tests
+                the kernel ran (the culling ratio) - not a bandwidth the kernel reaches.
   cpu_baseline  the CPU checker (oracle/, a float64 port of the same path) timed on this
                 host over a bounded sample of the same workload, OpenMP threads stated.
 """
@@ -30,6 +42,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+KERNEL_SOURCES = ("raytracer_amd/csrc/rt_kernels.hip", "raytracer_amd/csrc/rt_device.h", "include/raytracer_amd.h")
 
 WORKLOADS = {
     # name -> (scene, overrides)
@@ -42,6 +55,47 @@ WORKLOADS = {
 def algorithmic_bytes(c):
     rays = c["closest"] + c["shadow"]
     return 48 * rays + 16 * c["kd_nodes"] + 72 * c["tri_tests"] + 48 * c["analytic_tests"]
+
+
+def executed_bytes(c):
+    """Bytes the kernel's loads asked for in an RTAMD_COUNT_EXECUTED launch, plus ray and hit record."""
+    return 48 * (c["closest"] + c["shadow"]) + c["bytes_loaded"]
+
+
+def kernel_build_id():
+    """Hash of the kernel sources: ties a stored counter record to the library it was taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(REPO, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def profile_counters(args, log):
+    """Hardware counters of the tile kernel from profiled child processes (this process has
+    not touched the GPU yet), or the record under profiles/ made with the same kernel
+    sources, or None.  Returns (counters, source)."""
+    from raytracer_amd import profiling
+    stored = os.path.join(REPO, "profiles", "pmc_%s.json" % args.workload)
+    if not args.no_pmc:
+        cmd = [sys.executable, os.path.abspath(__file__), "--pmc-probe", "--workload", args.workload,
+               "--seed", str(args.seed), "--steps", "2", "--warmup", "1"]
+        t0 = time.time()
+        pmc = profiling.collect(cmd, log=log)
+        if pmc is not None:
+            pmc["build_id"] = kernel_build_id()
+            if args.save_pmc:
+                with open(stored, "w") as f:
+                    json.dump(pmc, f, indent=1, sort_keys=True)
+            return pmc, "rocprofv3 --pmc passes over a child process of this run (%.0f s)" % (time.time() - t0)
+    if os.path.exists(stored):
+        with open(stored) as f:
+            pmc = json.load(f)
+        if pmc.get("build_id") == kernel_build_id():
+            return pmc, "profiles/pmc_%s.json (same kernel sources)" % args.workload
+        log("profiles/pmc_%s.json was taken with other kernel sources: ignored" % args.workload)
+    return None, None
 
 
 def launch_ranks(n, argv):
@@ -69,12 +123,22 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes")
+    ap.add_argument("--save-pmc", action="store_true", help="store the counters under profiles/")
+    ap.add_argument("--pmc-probe", action="store_true", help=argparse.SUPPRESS)   # the profiled child
     args = ap.parse_args()
+
+    def log(msg):
+        print("[bench] " + msg, file=sys.stderr, flush=True)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process touches no GPU; it starts one fresh
         # process per GPU, lets rank 0's JSON line through and leaves with their status
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    pmc, pmc_source = None, None
+    if args.gpus == 1 and not args.pmc_probe and not os.environ.get("RTAMD_BENCH_LAUNCH_ONLY"):
+        pmc, pmc_source = profile_counters(args, log)
 
     import numpy
     import torch
@@ -157,6 +221,10 @@ def main():
 
     run(args.warmup)                            # same code path as the timed steps
     barrier()
+    if args.pmc_probe:                          # the child that rocprofv3 watches: kernels only
+        run(args.steps)
+        barrier()
+        return
     ds.read_counters(reset=True)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -177,20 +245,24 @@ def main():
     total_rays, total_samples = int(rays[0]), int(rays[1])
     rays_per_frame = total_rays / float(args.steps)
 
-    # roofline of the dominant (only) kernel on rank 0: one counting launch of this rank's share
+    # the dominant (only) kernel on rank 0: what it executes and what the reference would
+    # have done for the same rays, one counting launch each of this rank's share
     ds.read_counters(reset=True)
-    job.sum_rgb8.zero_()
-    ds.render_tiles(cam, world.seed, job.tile_ids, 0, n_samples, sum_rgb8=job.sum_rgb8, count_work=True)
+    probe = torch.zeros_like(job.sum_rgb8)
+    ds.render_tiles(cam, world.seed, job.tile_ids, 0, n_samples, sum_rgb8=probe, count_executed=True)
+    torch.cuda.synchronize()
+    done = ds.read_counters(reset=True, executed=True)
+    same_frame = bool(torch.equal(probe, bufs[(args.steps - 1) % 2]))     # against the last timed frame
+    probe.zero_()
+    ds.render_tiles(cam, world.seed, job.tile_ids, 0, n_samples, sum_rgb8=probe, count_work=True)
     torch.cuda.synchronize()
     work = ds.read_counters(reset=True)
     algo_bytes = algorithmic_bytes(work)
-    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-
-    traffic = None
-    traffic_file = os.path.join(REPO, "profiles", "traffic_%s.json" % args.workload)
-    if world_size == 1 and os.path.exists(traffic_file):     # measured for the whole-frame launch of one GPU
-        with open(traffic_file) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+    exec_bytes = executed_bytes(done)
+    n_rays = float(max(done["closest"] + done["shadow"], 1))
+    from raytracer_amd import profiling
+    ceil = profiling.ceilings(pmc if world_size == 1 else None, kernel_ms, exec_bytes)
+    hbm = ceil.get("hbm")
 
     cpu = None
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
@@ -219,17 +291,28 @@ def main():
                        "tiles": "8x8 px, diagonal interleave over ranks, RCCL gather to rank 0",
                        "scene_bytes": ds.flat.nbytes(), "host_scene_build_s": round(t_build, 2),
                        "frame_mean_rgb": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "trace_kernel<tiles>", "kernel_ms": kernel_ms,
-                         "note": "achieved = bytes the reference algorithm would move for these rays / kernel time; "
-                                 "the kernel answers most of those tests from bounding boxes and the scene stays "
-                                 "in cache, so it exceeds the HBM peak - traffic (PMC) is what HBM really moved",
-
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "algorithmic_bytes_per_ray": algo_bytes / float(max(work["closest"] + work["shadow"], 1)),
-                         "work_per_ray": {k: work[k] / float(max(work["closest"] + work["shadow"], 1))
-                                          for k in ("kd_nodes", "kd_leaves", "tri_tests", "analytic_tests")}},
+            "roofline": {"bound": "hbm",
+                         "achieved": hbm["achieved_GBs"] if hbm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": hbm["frac"] if hbm else None, "traffic": hbm["bytes_per_launch"] if hbm else None,
+                         "traffic_source": pmc_source,
+                         "kernel": (pmc or {}).get("kernel_name", "trace_kernel<tiles>"), "kernel_ms": kernel_ms,
+                         "binding": ceil.get("binding"),
+                         "ceilings": {k: v for k, v in ceil.items() if k != "binding"},
+                         "registers": {k: pmc[k] for k in ("vgpr", "accum_vgpr", "sgpr", "scratch", "lds") if pmc and k in pmc},
+                         "executed": {"bytes_per_launch": exec_bytes, "bytes_per_ray": exec_bytes / n_rays,
+                                      "same_frame_as_timed_kernel": same_frame,
+                                      "per_ray": {k: done[k] / n_rays for k in (
+                                          "kd_nodes", "kd_leaves", "leaves_skipped", "node_records", "boxes_tested",
+                                          "rows_loaded", "tri_tests", "analytic_tests")}},
+                         "reference_work": {"bytes_per_launch": algo_bytes, "bytes_per_ray": algo_bytes / n_rays,
+                                            "equivalent_GBs": algo_bytes / (kernel_ms * 1e-3) / 1e9,
+                                            "culling_ratio": work["tri_tests"] / float(max(done["tri_tests"], 1)),
+                                            "per_ray": {k: work[k] / n_rays for k in (
+                                                "kd_nodes", "kd_leaves", "tri_tests", "analytic_tests")}},
+                         "note": "hbm = counter-measured memory traffic of the launch / kernel time; l2 = bytes the "
+                                 "kernel's loads ask for / kernel time (upper bound on L2 traffic); valu = SIMD cycles "
+                                 "executing vector-ALU instructions; reference_work is the reference algorithm's "
+                                 "traffic for the same rays, most of which the kernel culls - not a rate it reaches"},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 3
+#define RTAMD_ABI_VERSION 4
 
 enum {
     RTAMD_OK = 0,
@@ -321,11 +321,22 @@ typedef struct rtamd_sample_out {
 
 /* Launch-wide counters, added to by every launch that is given the block:
  *   [0] closest-hit queries   [1] shadow queries      [2] samples traced
+ * With flags & RTAMD_COUNT_WORK the launch follows the REFERENCE algorithm step by step (no
+ * culling shortcut that would change the numbers) and adds what kdtree.py / geometry.py
+ * would spend on the same rays:
  *   [3] kd interior steps     [4] kd leaves visited   [5] triangle tests
- *   [6] analytic object tests [7] reserved
- * [3]-[6] are only maintained by rtamd_*_counted variants (flags & RTAMD_COUNT_WORK). */
-#define RTAMD_N_COUNTERS 8
+ *   [6] analytic object tests
+ * With flags & RTAMD_COUNT_EXECUTED the launch runs the same code as an uncounted one and adds
+ * what that code EXECUTES (per lane, summed):
+ *   [3] kd interior steps     [4] kd leaves reached   [5] ray-triangle tests run
+ *   [6] analytic object tests [7] leaves passed by because the ray misses the box of
+ *   their triangles           [8] node records loaded (a node and both children, 48 B)
+ *   [9] culling boxes tested  [10] triangle rows loaded (one row may be tested against
+ *   several rays)             [11] bytes requested by the loads behind [6], [8]-[10]
+ * The two flags exclude each other.  [12]-[15] are reserved. */
+#define RTAMD_N_COUNTERS 16
 #define RTAMD_COUNT_WORK 1u
+#define RTAMD_COUNT_EXECUTED 2u
 
 typedef struct rtamd_scene rtamd_scene;
 

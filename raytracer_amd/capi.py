@@ -7,10 +7,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(HERE, "csrc", "librtamd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_BRANCH_LEVELS = 8
-N_COUNTERS = 8
+N_COUNTERS = 16
 COUNT_WORK = 1
+COUNT_EXECUTED = 2
 
 SPHERE, PLANE, CHECKER_PLANE, RECTANGLE, BOX, TRIANGLE, KDTREE = range(7)
 CASTERS_ALL, CASTERS_NONE, CASTERS_MIXED = range(3)

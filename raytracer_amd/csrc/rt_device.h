@@ -107,27 +107,61 @@ struct WaveMarks {
 #else
 struct WaveMarks { __device__ __forceinline__ void mark(int) {} };
 #endif
-template <bool COUNT> struct Work : WaveMarks {
+// COUNT = 0: the timed kernels count rays only.  COUNT = 1: the work of the REFERENCE algorithm
+// (kd steps, leaves, triangle and analytic tests as kdtree.py / geometry.py would spend them);
+// such a launch also takes no shortcut that changes those numbers.  COUNT = 2: the work this
+// kernel EXECUTES on its fast path (the same code as COUNT = 0 plus the tallies): node records,
+// culling boxes and triangle rows loaded, ray-triangle tests run, bytes those loads ask for.
+template <int COUNT> struct Work : WaveMarks {
     uint32_t closest = 0, shadow = 0;
     __device__ __forceinline__ void node() {}
     __device__ __forceinline__ void leaf() {}
     __device__ __forceinline__ void tri(uint32_t) {}
     __device__ __forceinline__ void analytic() {}
-    __device__ __forceinline__ uint32_t nodes() const { return 0; }
-    __device__ __forceinline__ uint32_t leaves() const { return 0; }
-    __device__ __forceinline__ uint32_t tris() const { return 0; }
-    __device__ __forceinline__ uint32_t analytics() const { return 0; }
+    __device__ __forceinline__ void x_record() {}
+    __device__ __forceinline__ void x_box(uint32_t) {}
+    __device__ __forceinline__ void x_rows(uint32_t, uint32_t) {}
+    __device__ __forceinline__ void x_tests(uint32_t) {}
+    __device__ __forceinline__ void x_skip() {}
+    __device__ __forceinline__ void x_bytes(uint32_t) {}
+    __device__ __forceinline__ uint32_t slot(int) const { return 0; }
 };
-template <> struct Work<true> : WaveMarks {
+template <> struct Work<1> : WaveMarks {
     uint32_t closest = 0, shadow = 0, n_node = 0, n_leaf = 0, n_tri = 0, n_analytic = 0;
     __device__ __forceinline__ void node() { n_node++; }
     __device__ __forceinline__ void leaf() { n_leaf++; }
     __device__ __forceinline__ void tri(uint32_t k) { n_tri += k; }
     __device__ __forceinline__ void analytic() { n_analytic++; }
-    __device__ __forceinline__ uint32_t nodes() const { return n_node; }
-    __device__ __forceinline__ uint32_t leaves() const { return n_leaf; }
-    __device__ __forceinline__ uint32_t tris() const { return n_tri; }
-    __device__ __forceinline__ uint32_t analytics() const { return n_analytic; }
+    __device__ __forceinline__ void x_record() {}
+    __device__ __forceinline__ void x_box(uint32_t) {}
+    __device__ __forceinline__ void x_rows(uint32_t, uint32_t) {}
+    __device__ __forceinline__ void x_tests(uint32_t) {}
+    __device__ __forceinline__ void x_skip() {}
+    __device__ __forceinline__ void x_bytes(uint32_t) {}
+    __device__ __forceinline__ uint32_t slot(int i) const {
+        return i == 3 ? n_node : i == 4 ? n_leaf : i == 5 ? n_tri : i == 6 ? n_analytic : 0;
+    }
+};
+template <> struct Work<2> : WaveMarks {
+    uint32_t closest = 0, shadow = 0, n_node = 0, n_leaf = 0, n_test = 0, n_analytic = 0;
+    uint32_t n_skip = 0, n_record = 0, n_box = 0, n_row = 0, n_byte = 0;
+    __device__ __forceinline__ void node() { n_node++; }                     // interior steps taken
+    __device__ __forceinline__ void leaf() { n_leaf++; }                     // leaves reached
+    __device__ __forceinline__ void tri(uint32_t) {}
+    __device__ __forceinline__ void analytic() { n_analytic++; n_byte += 48; }
+    __device__ __forceinline__ void x_record() { n_record++; n_byte += 48; } // node + both children, 3 x 16 B
+    __device__ __forceinline__ void x_box(uint32_t bytes) { n_box++; n_byte += bytes; }
+    __device__ __forceinline__ void x_rows(uint32_t k, uint32_t bytes_each) { n_row += k; n_byte += k * bytes_each; }
+    __device__ __forceinline__ void x_tests(uint32_t k) { n_test += k; }
+    __device__ __forceinline__ void x_skip() { n_skip++; }
+    __device__ __forceinline__ void x_bytes(uint32_t b) { n_byte += b; }
+    __device__ __forceinline__ uint32_t slot(int i) const {
+        switch (i) {
+        case 3: return n_node; case 4: return n_leaf; case 5: return n_test; case 6: return n_analytic;
+        case 7: return n_skip; case 8: return n_record; case 9: return n_box; case 10: return n_row;
+        case 11: return n_byte; default: return 0;
+        }
+    }
 };
 
 // ---------------------------------------------------------------- wave helpers
@@ -304,7 +338,7 @@ struct TriHit { double t, alpha, beta; int32_t ref; };
 // that lane's leaf with one row per group lane and reduces inside the group; the pending
 // lane then collects its group's result.  Rows of such leaves are stored in scan order,
 // so the scan position of a row is its lane's position in the group.
-template <bool COUNT, bool SHADOW, int W>
+template <int COUNT, bool SHADOW, int W>
 __device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, bool flagged, unsigned long long pending,
                                               const Ray& r, int32_t first, int32_t count, Work<COUNT>& w,
                                               bool& found, TriHit& best) {
@@ -336,6 +370,8 @@ __device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, bool fl
         if (SHADOW && flagged) usable = in && !(S.tri_prim[ref] & NO_SHADOW_BIT);         // geometry.py:433-434
         double a = 0, b = 0, t = 0;
         const bool hit = usable && tri_solve_ref(geom, ref, q, a, b, t);
+        w.x_rows(usable ? 1u : 0u, 72);
+        w.x_tests(usable ? 1u : 0u);
         const unsigned long long hm = __ballot(hit);
         const unsigned long long group_mask = (1ull << W) - 1ull;
         bool g_found = false;
@@ -365,13 +401,13 @@ __device__ __forceinline__ void packed_leaves(const rtamd_scene_desc& S, bool fl
             }
         }
         uint32_t g_tests = 0;
-        if (COUNT && SHADOW) {
+        if (COUNT == 1 && SHADOW) {
             const uint32_t ub = (uint32_t)((__ballot(usable) >> (grp * W)) & group_mask);
             g_tests = g_found ? (uint32_t)__popc(ub & ((2u << g_sub) - 1u)) : (uint32_t)__popc(ub);
         }
         // hand the group results to the lanes that own the rays
         const int from = (my_group < 0 ? 0 : my_group) * W;
-        if (COUNT) {
+        if (COUNT == 1) {
             const uint32_t n = SHADOW ? (uint32_t)__shfl((int)g_tests, from) : (uint32_t)count;
             if (my_group >= 0) w.tri(n);
         }
@@ -434,20 +470,26 @@ __device__ __forceinline__ bool box_touch_f_second(const float* p, const Ray& q,
 // cell.  A box the ray enters beyond the best t so far cannot hold a closer or equal hit.
 // Meant for waves whose rays are close together (primary rays of a tile): their lanes read
 // the same boxes and rows, so the loads coalesce.
+template <int COUNT>
 __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& S, const Ray& r, int32_t first,
-                                                        int32_t count, int32_t cbase, bool& found, TriHit& best) {
+                                                        int32_t count, int32_t cbase, Work<COUNT>& w, bool& found,
+                                                        TriHit& best) {
     const V3 inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     const int32_t n_chunks = (count + 63) >> 6;
     int32_t best_ord = 0;
     for (int32_t j = 0; j < n_chunks; ++j) {
         const double* rec = S.leaf_boxes + (int64_t)(cbase + j) * 54;
         double tn;
+        w.x_box(48);
         if (!box_touch(rec, r, inv, tn) || (found && tn > best.t)) continue;
         const int32_t rows_here = min(64, count - (j << 6));
         for (int32_t k = 0; k * 8 < rows_here; ++k) {
+            w.x_box(48);
             if (!box_touch(rec + 6 * (1 + k), r, inv, tn) || (found && tn > best.t)) continue;
             const int32_t r0 = first + (j << 6) + k * 8;
             const int32_t nr = min(8, rows_here - k * 8);
+            w.x_rows((uint32_t)nr, 80);
+            w.x_tests((uint32_t)nr);
             for (int32_t i = 0; i < nr; ++i) {
                 const TriRow row = load_row(S, r0 + i);
                 double a, b, t;
@@ -478,7 +520,7 @@ __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& 
 // strict minimum t wins, ties go to the earlier item, and the walk ends at the first leaf
 // with a hit.  SHADOW = true is KDTree.shadow_hit (kdtree.py:157-164): the first item in
 // leaf order that reports a hit ends the query and its t is returned.
-template <bool COUNT, bool SHADOW>
+template <int COUNT, bool SHADOW>
 __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool active, const Ray& ray_in,
                               double limit_in, bool coherent, const KdStack& stk, Work<COUNT>& w, bool& found,
                               TriHit& best) {
@@ -492,7 +534,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     // reference's work)
     const bool flagged = SHADOW && T.shadow_casters != RTAMD_CASTERS_ALL;
     const bool lane_scans = !SHADOW && coherent && S.leaf_boxes != nullptr;
-    if (SHADOW && !COUNT && T.shadow_casters == RTAMD_CASTERS_NONE) return;
+    if (SHADOW && COUNT != 1 && T.shadow_casters == RTAMD_CASTERS_NONE) return;
     double t_near = 0, t_far = 0, t_exit = 0;
     bool walking = active && root_box(T, r, t_near, t_exit);
     t_far = t_exit;
@@ -507,7 +549,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     const bool use_leaf_aabb = S.leaf_aabb != nullptr && T.depth >= 8;
     V3 inv_d = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
 #ifndef RT_NO_STEAL
-    constexpr bool STEAL = SHADOW && !COUNT;
+    constexpr bool STEAL = SHADOW && COUNT != 1;
 #else
     constexpr bool STEAL = false;
 #endif
@@ -616,6 +658,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 // a 64-byte record holds a node and both its children, so every load serves two levels
                 const rtamd_kdnode* rec = S.kd_triples + (int64_t)node * 4;
                 rtamd_kdnode nd = rec[0], left = rec[1], right = rec[2];
+                w.x_record();
                 while ((nd.b & 3) != 3) {
                     const int32_t left_index = node + 1;
                     step(nd);
@@ -626,6 +669,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                     if (STEAL && ++loads >= RT_MAX_LOADS) { parked = true; break; }
                     rec = S.kd_triples + (int64_t)node * 4;
                     nd = rec[0]; left = rec[1]; right = rec[2];
+                    w.x_record();
                 }
                 if (parked) break;
                 w.leaf();
@@ -635,10 +679,12 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
 #ifndef RT_NO_LEAF_AABB
                 // a leaf of up to 64 rows whose triangles' box the ray misses holds no hit: the
                 // lane walks on at once (not when counting: the reference tests the rows)
-                if (!COUNT && use_leaf_aabb && count <= 64) {
+                if (COUNT != 1 && use_leaf_aabb && count <= 64) {
                     double tn;
                     double tf;
+                    if (count != 0) w.x_box(32);
                     if (count == 0 || !box_touch_f(S.leaf_aabb + (int64_t)node * 8, r, inv_d, tn, tf)) {
+                        w.x_skip();
                         if (sp == sb) { walking = false; first = 0; count = 0; cbase = -1; break; }
                         pop();
                         // a long run of skipped leaves ends the lane's round without a leaf, so
@@ -663,13 +709,17 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
             if (SHADOW) {
                 for (int32_t i = 0; i < count; ++i) {
                     const TriRow row = load_row(S, first + i);
+                    w.x_rows(1, 80);
                     if (row.prim & NO_SHADOW_BIT) continue;                      // geometry.py:433-434
                     w.tri(1);
+                    w.x_tests(1);
                     double a, b, t;
                     if (tri_solve_v(row.v0, row.e1, row.e2, r, a, b, t)) { best.t = t; found = true; break; }
                 }
             } else {
                 w.tri((uint32_t)count);
+                w.x_rows((uint32_t)count, 80);
+                w.x_tests((uint32_t)count);
                 for (int32_t i = 0; i < count; ++i) {
                     const TriRow row = load_row(S, first + i);
                     double a, b, t;
@@ -712,7 +762,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
             const unsigned long long pm = __ballot(mine);
             if (pm) {
                 if (mine) {
-                    boxed_leaf_closest_lane(S, r, first, count, cbase, found, best);
+                    boxed_leaf_closest_lane<COUNT>(S, r, first, count, cbase, w, found, best);
                     w.tri((uint32_t)count);
                 }
                 big &= ~pm;
@@ -737,9 +787,11 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
             const float* rec = S.chunk_tree + (int64_t)cbase * 12;
             double tf;
             for (int32_t g = 0; g < nch; g += 4) {
+                if (nch > 4) w.x_box(32);
                 if (nch > 4 && !box_touch_f_second(rec + g * 12, r, inv, tn, tf)) continue;
                 const int32_t g_end = min(g + 4, nch);
                 for (int32_t j = g; j < g_end; ++j) {
+                    w.x_box(32);
                     if (box_touch_f(rec + j * 12, r, inv, tn, tf)) {
                         my_chunks |= 1ull << j;
                         if (!(tf < limit)) my_any_hit_decides = false;
@@ -757,7 +809,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         // leaf of 33-64 rows without boxes counts as one chunk.  A ray whose boxes all end
         // before its limit is decided by any hit (see below); the others keep the hit with
         // the earliest scan position over all their chunks, as KDTree.shadow_hit reports it.
-        if (SHADOW && !COUNT && prepass) {
+        if (SHADOW && COUNT != 1 && prepass) {
             const bool eligible = at_leaf && !small && count > 32 && (cbase < 0 ? count <= 64 : count <= 4096);
             if (eligible && cbase < 0) { my_chunks = 1; my_any_hit_decides = false; }
             const bool has_work = eligible && my_chunks != 0;
@@ -791,6 +843,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                     const V3 v0 = v3(tri_component(geom, off, 0), tri_component(geom, off, 1), tri_component(geom, off, 2));
                     const V3 e1 = v3(tri_component(geom, off, 3), tri_component(geom, off, 4), tri_component(geom, off, 5));
                     const V3 e2 = v3(tri_component(geom, off, 6), tri_component(geom, off, 7), tri_component(geom, off, 8));
+                    w.x_rows(in ? 1u : 0u, 72);
                     while (takers) {
                         const int rl = first_lane(takers);
                         takers &= takers - 1;
@@ -799,6 +852,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                         q.d = v3(bcast_d(r.d.x, rl), bcast_d(r.d.y, rl), bcast_d(r.d.z, rl));
                         double a, b, t;
                         const bool hit = usable && tri_solve_v(v0, e1, e2, q, a, b, t);
+                        w.x_tests(usable ? 1u : 0u);
                         const unsigned long long hm = __ballot(hit);
                         if (!hm) continue;
                         if (bcast_i((int)my_any_hit_decides, rl) != 0) {
@@ -881,13 +935,15 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 bool usable = in;
                 if (SHADOW && flagged) usable = in && !(S.tri_prim[in ? ref : qfirst] & NO_SHADOW_BIT);   // geometry.py:433-434
                 double a, b, t;
+                w.x_rows(usable ? 1u : 0u, 72);
+                w.x_tests(usable ? 1u : 0u);
                 if (usable && tri_solve_ref(geom, ref, q, a, b, t)) {
                     const int32_t ord = S.tri_order ? S.tri_order[ref] : ref;
                     const bool better = SHADOW ? (!lfound || ord < lord)
                                                : (!lfound || t < lt || (t == lt && ord < lord));
                     if (better) { lt = t; la = a; lb = b; lref = ref; lord = ord; lfound = true; }
                 }
-                if (COUNT && SHADOW && qbox < 0) {
+                if (COUNT == 1 && SHADOW && qbox < 0) {
                     // rows are in scan order here: the reference stops at the first hit
                     const unsigned long long hm = __ballot(lfound), um = __ballot(usable);
                     if (hm) { tests += (uint32_t)__popcll(um & ((2ull << first_lane(hm)) - 1ull)); }
@@ -902,7 +958,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 const uint32_t lo = (uint32_t)bcast_i((int)(uint32_t)my_chunks, src);
                 const uint32_t hi = (uint32_t)bcast_i((int)(uint32_t)(my_chunks >> 32), src);
                 unsigned long long todo = ((unsigned long long)hi << 32) | lo;
-                const bool any_hit_decides = !COUNT && bcast_i((int)my_any_hit_decides, src) != 0;
+                const bool any_hit_decides = COUNT != 1 && bcast_i((int)my_any_hit_decides, src) != 0;
                 while (todo) {
                     const int32_t c = (int32_t)__builtin_ctzll(todo) << 6;
                     todo &= todo - 1;
@@ -925,6 +981,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                     bool touch = false;
                     double tf = 0;
                     if (j < n_chunks) {
+                        w.x_box(48);
                         const double* bx = cb + qbox + j;
                         const double x0 = (bx[0] - q.o.x) * ix, x1 = (bx[3 * nc] - q.o.x) * ix;
                         const double y0 = (bx[nc] - q.o.y) * iy, y1 = (bx[4 * nc] - q.o.y) * iy;
@@ -935,7 +992,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                         touch = !(tn > tf) && !(tf < 0.0);
                     }
                     unsigned long long todo = __ballot(touch);
-                    const bool any_hit_decides = SHADOW && !COUNT && n_chunks <= 64 && !__ballot(touch && !(tf < qlimit));
+                    const bool any_hit_decides = SHADOW && COUNT != 1 && n_chunks <= 64 && !__ballot(touch && !(tf < qlimit));
                     while (todo) {
                         const int32_t c = (c0 + first_lane(todo)) << 6;
                         todo &= todo - 1;
@@ -967,7 +1024,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 const double wt = bcast_d(lt, winner), wa = bcast_d(la, winner), wb = bcast_d(lb, winner);
                 const int32_t wr = bcast_i(lref, winner);
                 if (lane == src) { best.t = wt; best.alpha = wa; best.beta = wb; best.ref = wr; found = true; }
-                if (COUNT && SHADOW && qbox >= 0) {
+                if (COUNT == 1 && SHADOW && qbox >= 0) {
                     // what the reference's scan would have tested: shadow casters up to the hit
                     const int32_t ow = bcast_i(lord, winner);
                     for (int32_t c = 0; c < qcount; c += 64) {
@@ -977,7 +1034,7 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                         tests += (uint32_t)__popcll(__ballot(counted));
                     }
                 }
-            } else if (COUNT && SHADOW && qbox >= 0) {
+            } else if (COUNT == 1 && SHADOW && qbox >= 0) {
                 for (int32_t c = 0; c < qcount; c += 64) {
                     const int32_t i = c + lane;
                     const bool counted = i < qcount && !(S.tri_prim[qfirst + (i < qcount ? i : 0)] & NO_SHADOW_BIT);
@@ -1126,7 +1183,7 @@ struct Hit {
 };
 
 // World.hit_objects (main.py:35-46) for every active lane: objects in list order, strict `<`.
-template <bool COUNT, bool TREES>
+template <int COUNT, bool TREES>
 __device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, bool active, bool coherent, const Ray& ray,
                                  Work<COUNT>& w, Hit& h) {
     if (active) w.closest++;
@@ -1231,7 +1288,7 @@ __device__ __forceinline__ bool analytic_shadow(const rtamd_object& ob, const Ra
     }
 }
 
-template <bool COUNT, bool TREES, bool ONE_TREE = false>
+template <int COUNT, bool TREES, bool ONE_TREE = false>
 __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, bool need, const Ray& ray,
                               bool use_limit, double limit, Work<COUNT>& w) {
     if (need) w.shadow++;
@@ -1248,6 +1305,7 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
             if (!(need && !occ && ob.cast_shadow)) continue;
             const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
             double t = 0;
+            w.analytic();
             if (analytic_shadow(ob, r, t) && (!use_limit || t < limit)) occ = true;
         }
         const rtamd_object& ob = S.objects[tree_object];
@@ -1261,7 +1319,7 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
         }
         return occ;
     }
-    if (TREES && !COUNT) {
+    if (TREES && COUNT != 1) {
         // "any object" does not depend on the order: the cheap analytic objects first, so that
         // a ray they occlude never walks a tree (a counting launch keeps the list order, which
         // decides how much work the reference does)
@@ -1270,12 +1328,13 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
             if (ob.kind == RTAMD_KDTREE || !(need && !occ && ob.cast_shadow)) continue;
             const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
             double t = 0;
+            w.analytic();
             if (analytic_shadow(ob, r, t) && (!use_limit || t < limit)) occ = true;
         }
     }
     for (int i = 0; i < S.n_objects; ++i) {
         const rtamd_object& ob = S.objects[i];
-        if (TREES && !COUNT && ob.kind != RTAMD_KDTREE) continue;
+        if (TREES && COUNT != 1 && ob.kind != RTAMD_KDTREE) continue;
         const bool q = need && !occ;
         const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
         double t = 0;
@@ -1350,7 +1409,7 @@ __device__ __forceinline__ V3 texture_color(const rtamd_scene_desc& S, int tex, 
 // visited in list order by the whole wave so that the shadow queries stay wave-wide.
 // EXT: `tex` is the texture colour of an SV_Matte hit (material.py:311-326), which scales
 // ka and kd and adds the viewer-side test of :319.
-template <bool COUNT, bool EXT, bool TREES, bool ONE_TREE = false>
+template <int COUNT, bool EXT, bool TREES, bool ONE_TREE = false>
 __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, bool lit, const rtamd_material& m,
                                 const Hit& h, V3 wo, bool area, V3 tex, Draw& dr, Work<COUNT>& w) {
     // ambient_color.L(sr): AmbientLight (light.py:14-15) or AmbientOccluder (light.py:85-100)
@@ -1488,7 +1547,7 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(pow(b.x, e), pow(
 // the compiler then drops the bounce loop and the ray and weight it would carry through the
 // shadow queries.  The instantiation is launched for scenes with exactly one kd-tree object,
 // which the shadow tests then ask last (occluded_wave<..., ONE_TREE>), and exactly one light.
-template <bool COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
+template <int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
 __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, Primary& first) {
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);

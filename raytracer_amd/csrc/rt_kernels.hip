@@ -117,7 +117,7 @@ __device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point,
 // do not pay for.
 // TREES = false instantiations serve scenes without a kd-tree (analytic primitives only):
 // no traversal code, no LDS stack, and the registers go to the shading loop.
-template <int MODE, bool COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
+template <int MODE, int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
 __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
     // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
@@ -242,15 +242,15 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
         __shared__ unsigned int blk[RTAMD_N_COUNTERS];
         if (threadIdx.x < RTAMD_N_COUNTERS) blk[threadIdx.x] = 0;
         __syncthreads();
-        const unsigned int vals[7] = {work.closest, work.shadow, live ? 1u : 0u, work.nodes(),
-                                      work.leaves(), work.tris(), work.analytics()};
-        for (int i = 0; i < 7; ++i) {
-            unsigned int v = vals[i];
+        constexpr int N_USED = COUNT == 2 ? 12 : (COUNT == 1 ? 7 : 3);
+#pragma unroll
+        for (int i = 0; i < N_USED; ++i) {
+            unsigned int v = i == 0 ? work.closest : i == 1 ? work.shadow : i == 2 ? (live ? 1u : 0u) : work.slot(i);
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if ((threadIdx.x & 63) == 0 && v) atomicAdd(&blk[i], v);
         }
         __syncthreads();
-        if (threadIdx.x < 7 && blk[threadIdx.x]) atomicAdd(&A.counters[threadIdx.x], (unsigned long long)blk[threadIdx.x]);
+        if (threadIdx.x < N_USED && blk[threadIdx.x]) atomicAdd(&A.counters[threadIdx.x], (unsigned long long)blk[threadIdx.x]);
     }
 }
 
@@ -282,21 +282,31 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, LaunchArg
     if (blocks > 0x7fffffffLL) return fail(RTAMD_EINVAL, "too many samples for one launch%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool count = (flags & RTAMD_COUNT_WORK) != 0;
+    const bool executed = (flags & RTAMD_COUNT_EXECUTED) != 0;
+    if (count && executed) return fail(RTAMD_EINVAL, "RTAMD_COUNT_WORK and RTAMD_COUNT_EXECUTED exclude each other%s");
+    if (executed && !A.counters) return fail(RTAMD_EINVAL, "RTAMD_COUNT_EXECUTED needs a counter block%s");
     const dim3 grid((unsigned)blocks), block(BLOCK);
-    if (extended) {
-        if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, true, true>), grid, block, 0, st, S, A);
-        else hipLaunchKernelGGL((trace_kernel<MODE, false, true, true>), grid, block, 0, st, S, A);
-    } else if (trees) {
-        if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false, true>), grid, block, 0, st, S, A);
+    // the whole-frame case of a single tree under the AreaLightTracer with a single light has a kernel of its own
+    bool area_only = false;
 #ifndef RT_NO_AREA_ONLY
-        else if (MODE == MODE_TILES && S.tracer_kind == RTAMD_TRACER_AREA && tree_objects == 1 && S.n_lights == 1 && !A.out.rgb && !A.out.rgb8 &&
-                 !A.out.hit_object && !A.out.hit_prim && !A.out.hit_t && !A.out.n_rays)
-            hipLaunchKernelGGL((trace_kernel<MODE, false, false, true, true>), grid, block, 0, st, S, A);
+    area_only = MODE == MODE_TILES && !extended && trees && S.tracer_kind == RTAMD_TRACER_AREA && tree_objects == 1 &&
+                S.n_lights == 1 && !A.out.rgb && !A.out.rgb8 && !A.out.hit_object && !A.out.hit_prim && !A.out.hit_t &&
+                !A.out.n_rays;
 #endif
-        else hipLaunchKernelGGL((trace_kernel<MODE, false, false, true>), grid, block, 0, st, S, A);
+    if (extended) {
+        if (count) hipLaunchKernelGGL((trace_kernel<MODE, 1, true, true>), grid, block, 0, st, S, A);
+        else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, true, true>), grid, block, 0, st, S, A);
+        else hipLaunchKernelGGL((trace_kernel<MODE, 0, true, true>), grid, block, 0, st, S, A);
+    } else if (trees) {
+        if (count) hipLaunchKernelGGL((trace_kernel<MODE, 1, false, true>), grid, block, 0, st, S, A);
+        else if (area_only && executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 2, false, true, true>), grid, block, 0, st, S, A);
+        else if (area_only) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
+        else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, false, true>), grid, block, 0, st, S, A);
+        else hipLaunchKernelGGL((trace_kernel<MODE, 0, false, true>), grid, block, 0, st, S, A);
     } else {
-        if (count) hipLaunchKernelGGL((trace_kernel<MODE, true, false, false>), grid, block, 0, st, S, A);
-        else hipLaunchKernelGGL((trace_kernel<MODE, false, false, false>), grid, block, 0, st, S, A);
+        if (count) hipLaunchKernelGGL((trace_kernel<MODE, 1, false, false>), grid, block, 0, st, S, A);
+        else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, false, false>), grid, block, 0, st, S, A);
+        else hipLaunchKernelGGL((trace_kernel<MODE, 0, false, false>), grid, block, 0, st, S, A);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
@@ -491,8 +501,19 @@ int rtamd_scene_destroy(rtamd_scene* scene) {
     return RTAMD_OK;
 }
 
+// A handle's tables live on the device that was current when it was created; a launch from
+// another device would hand that device's kernel foreign pointers.
+static int check_device(const rtamd_scene* scene) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (dev != scene->device) return fail(RTAMD_EINVAL, "the scene belongs to another device than the current one%s");
+    return RTAMD_OK;
+}
+
 static int check_camera(const rtamd_scene* scene, const rtamd_camera* c) {
     if (!scene || !c) return fail(RTAMD_EINVAL, "null scene or camera%s");
+    if (int rc = check_device(scene)) return rc;
     if (c->width <= 0 || c->height <= 0) return fail(RTAMD_EINVAL, "empty view plane%s");
     if (c->sampler < 0 || c->sampler >= scene->desc.n_samplers) return fail(RTAMD_EINVAL, "camera sampler out of range%s");
     return RTAMD_OK;
@@ -528,6 +549,7 @@ int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t
                      int32_t depth, const rtamd_sample_out* out, uint64_t* counters, uint32_t flags,
                      void* stream) {
     if (!scene) return fail(RTAMD_EINVAL, "null scene%s");
+    if (int rc = check_device(scene)) return rc;
     if (n < 0) return fail(RTAMD_EINVAL, "negative ray count%s");
     if (n == 0) return RTAMD_OK;
     if (!origins || !directions || !out) return fail(RTAMD_EINVAL, "null ray buffer%s");

@@ -59,6 +59,8 @@ class DeviceScene(object):
             desc.leaf_aabb = self.tensors["leaf_aabb"].data_ptr()
             desc.n_chunks = n_chunks
             handle = C.c_void_p()
+            # the library reads the small tables back on the null stream: the uploads must have landed
+            torch.cuda.current_stream(self.device).synchronize()
             capi.check(self.lib.rtamd_scene_create(C.byref(desc), C.byref(handle)), self.lib)
         self.handle = handle
         self.counters = torch.zeros(capi.N_COUNTERS, dtype=torch.int64, device=self.device)
@@ -75,6 +77,11 @@ class DeviceScene(object):
             pass
 
     # -- helpers ---------------------------------------------------------------------
+    def on_device(self):
+        """Context in which the scene's own device is the current one (the library refuses
+        a launch from any other)."""
+        return _torch().cuda.device(self.device)
+
     def stream_ptr(self):
         torch = _torch()
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -95,16 +102,26 @@ class DeviceScene(object):
             setattr(out, k, t.data_ptr())
         return bufs, out
 
-    def read_counters(self, reset=True):
+    COUNTER_NAMES = ("closest", "shadow", "samples", "kd_nodes", "kd_leaves", "tri_tests", "analytic_tests")
+    EXECUTED_NAMES = COUNTER_NAMES + ("leaves_skipped", "node_records", "boxes_tested", "rows_loaded", "bytes_loaded")
+
+    def read_counters(self, reset=True, executed=False):
+        """Launch-wide counters since the last reset.  With `executed` the slots a
+        count_executed launch fills are named as well (include/raytracer_amd.h)."""
         vals = self.counters.cpu().numpy().copy()
         if reset:
             self.counters.zero_()
-        return dict(zip(("closest", "shadow", "samples", "kd_nodes", "kd_leaves", "tri_tests", "analytic_tests"),
-                        (int(v) for v in vals[:7])))
+        names = self.EXECUTED_NAMES if executed else self.COUNTER_NAMES
+        return dict(zip(names, (int(v) for v in vals[:len(names)])))
+
+    @staticmethod
+    def _flags(count_work, count_executed):
+        return (capi.COUNT_WORK if count_work else 0) | (capi.COUNT_EXECUTED if count_executed else 0)
 
     # -- the three entry points ------------------------------------------------------
     def render_pixels(self, cam, seed, pixel_index, sample_index, plane_points, lens_points=None,
-                      want=("rgb", "rgb8", "hit_object", "hit_prim", "hit_t", "n_rays"), count_work=False):
+                      want=("rgb", "rgb8", "hit_object", "hit_prim", "hit_t", "n_rays"), count_work=False,
+                      count_executed=False):
         n = len(pixel_index)
         bufs, out = self.sample_buffers(n, want)
         if n:
@@ -112,14 +129,15 @@ class DeviceScene(object):
             si = self.to_device(sample_index, numpy.int32)
             pp = self.to_device(plane_points, numpy.float64)
             lp = self.to_device(lens_points, numpy.float64) if lens_points is not None else None
-            capi.check(self.lib.rtamd_render_pixels(
-                self.handle, C.byref(cam), seed, n, pi.data_ptr(), si.data_ptr(), pp.data_ptr(),
-                lp.data_ptr() if lp is not None else None, C.byref(out), self.counters.data_ptr(),
-                capi.COUNT_WORK if count_work else 0, self.stream_ptr()), self.lib)
+            with self.on_device():
+                capi.check(self.lib.rtamd_render_pixels(
+                    self.handle, C.byref(cam), seed, n, pi.data_ptr(), si.data_ptr(), pp.data_ptr(),
+                    lp.data_ptr() if lp is not None else None, C.byref(out), self.counters.data_ptr(),
+                    self._flags(count_work, count_executed), self.stream_ptr()), self.lib)
         return {k: v[:n].cpu().numpy() for k, v in bufs.items()}
 
     def trace_rays(self, seed, origins, directions, pixel_index=None, sample_index=None, depth=0,
-                   want=("rgb", "hit_object", "hit_prim", "hit_t", "n_rays"), count_work=False):
+                   want=("rgb", "hit_object", "hit_prim", "hit_t", "n_rays"), count_work=False, count_executed=False):
         n = len(origins)
         bufs, out = self.sample_buffers(n, want)
         if n:
@@ -127,23 +145,25 @@ class DeviceScene(object):
             d = self.to_device(directions, numpy.float64)
             pi = self.to_device(pixel_index, numpy.int32) if pixel_index is not None else None
             si = self.to_device(sample_index, numpy.int32) if sample_index is not None else None
-            capi.check(self.lib.rtamd_trace_rays(
-                self.handle, seed, n, pi.data_ptr() if pi is not None else None,
-                si.data_ptr() if si is not None else None, o.data_ptr(), d.data_ptr(), depth,
-                C.byref(out), self.counters.data_ptr(), capi.COUNT_WORK if count_work else 0,
-                self.stream_ptr()), self.lib)
+            with self.on_device():
+                capi.check(self.lib.rtamd_trace_rays(
+                    self.handle, seed, n, pi.data_ptr() if pi is not None else None,
+                    si.data_ptr() if si is not None else None, o.data_ptr(), d.data_ptr(), depth,
+                    C.byref(out), self.counters.data_ptr(), self._flags(count_work, count_executed),
+                    self.stream_ptr()), self.lib)
         return {k: v[:n].cpu().numpy() for k, v in bufs.items()}
 
     def render_tiles(self, cam, seed, tile_ids, sample_begin, sample_end, sum_rgb8=None, sum_sq=None,
-                     per_sample=None, count_work=False):
+                     per_sample=None, count_work=False, count_executed=False):
         """Asynchronous: accumulates into the given device tensors on the current stream."""
         out = per_sample[1] if per_sample is not None else None
-        capi.check(self.lib.rtamd_render_tiles(
-            self.handle, C.byref(cam), seed, tile_ids.numel(), tile_ids.data_ptr(), sample_begin, sample_end,
-            C.byref(out) if out is not None else None,
-            sum_rgb8.data_ptr() if sum_rgb8 is not None else None,
-            sum_sq.data_ptr() if sum_sq is not None else None,
-            self.counters.data_ptr(), capi.COUNT_WORK if count_work else 0, self.stream_ptr()), self.lib)
+        with self.on_device():
+            capi.check(self.lib.rtamd_render_tiles(
+                self.handle, C.byref(cam), seed, tile_ids.numel(), tile_ids.data_ptr(), sample_begin, sample_end,
+                C.byref(out) if out is not None else None,
+                sum_rgb8.data_ptr() if sum_rgb8 is not None else None,
+                sum_sq.data_ptr() if sum_sq is not None else None,
+                self.counters.data_ptr(), self._flags(count_work, count_executed), self.stream_ptr()), self.lib)
 
 
 def device_scene(world):
