@@ -16,7 +16,10 @@ namespace rt {
 constexpr double EPS = 1.0e-7;                    // geometry.py:8, tracer.py:4, kdtree.py:5
 constexpr double T_INF = 9223372036854775807.0;   // sys.maxint, the initial tmin (main.py:37)
 constexpr double PI = 3.141592653589793;
-constexpr int STACK_MAX = 64;                     // >= tree depth + 2, checked on the host
+#ifndef RT_STACK_MAX
+#define RT_STACK_MAX 40
+#endif
+constexpr int STACK_MAX = RT_STACK_MAX;           // >= tree depth + 2, checked on the host
 constexpr int NO_SHADOW_BIT = 1 << 30;
 
 // ---------------------------------------------------------------- small vector type
@@ -290,7 +293,10 @@ enum { PH_DESCENT = 0, PH_PACK16 = 1, PH_PACK32 = 2, PH_BIG_PLAIN = 3, PH_BIG_BO
 // the root box's exit distance for the bottom entry), so it is recovered on pop instead
 // of being stored.  The first LDS_STACK entries of every lane live in LDS, lane-
 // interleaved (conflict-free); deeper entries go to per-lane private memory.
-constexpr int LDS_STACK = 10;
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 10
+#endif
+constexpr int LDS_STACK = RT_LDS_STACK;
 struct KdStack {
     int32_t* node;      // LDS, [LDS_STACK][64]
     double* t;          // LDS, [LDS_STACK][64]
@@ -1620,6 +1626,9 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
             tex = texture_color(S, m.texture, local_hit_point(S.objects[h.object], ray, h.t));
         const V3 Ld = direct_light_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, alive, m, h, wo, area, tex, dr, w);
         if (alive) L = L + W * Ld;
+        // the AreaLightTracer never bounces: leaving here makes the body straight-line code, so
+        // nothing is hoisted in front of it and carried (or spilled) through the kd queries
+        if (AREA_ONLY) break;
         if (area) { alive = false; continue; }
         if (!alive) continue;
 

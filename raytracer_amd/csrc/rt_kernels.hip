@@ -213,18 +213,38 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_
             if (A.out.hit_t) A.out.hit_t[ko] = first.t;
             if (A.out.n_rays) { A.out.n_rays[2 * ko] = (int32_t)work.closest; A.out.n_rays[2 * ko + 1] = (int32_t)work.shadow; }
             }
-            if (MODE == MODE_TILES) {
-                if (A.sum_rgb8) {
-                    unsigned long long* s = reinterpret_cast<unsigned long long*>(A.sum_rgb8) + 3 * acc_row;
-                    atomicAdd(s, (unsigned long long)(long long)r8);
-                    atomicAdd(s + 1, (unsigned long long)(long long)g8);
-                    atomicAdd(s + 2, (unsigned long long)(long long)b8);
+        }
+        if (MODE == MODE_TILES) {
+            // The 2^group_shift samples of a pixel that share this wave sit in lanes a multiple
+            // of 64 >> group_shift apart (tile_slot): their contributions are summed across
+            // those lanes first, and the lane of the pixel's first sample adds the total, so
+            // the accumulators see one atomic per pixel, channel and wave.  All lanes of a
+            // pixel are live or dead together (liveness depends on the pixel alone).
+            const int32_t stride = 64 >> A.group_shift;
+            const bool adds = live && (int32_t)threadIdx.x < stride;
+            if (A.sum_rgb8) {
+                long long r = live ? (long long)quantise(c.x) : 0, g = live ? (long long)quantise(c.y) : 0,
+                          b = live ? (long long)quantise(c.z) : 0;
+                for (int32_t off = stride; off < 64; off <<= 1) {
+                    r += __shfl_xor(r, off); g += __shfl_xor(g, off); b += __shfl_xor(b, off);
                 }
-                if (A.sum_sq) {
+                if (adds) {
+                    unsigned long long* s = reinterpret_cast<unsigned long long*>(A.sum_rgb8) + 3 * acc_row;
+                    atomicAdd(s, (unsigned long long)r);
+                    atomicAdd(s + 1, (unsigned long long)g);
+                    atomicAdd(s + 2, (unsigned long long)b);
+                }
+            }
+            if (A.sum_sq) {
+                double r = live ? c.x * c.x : 0.0, g = live ? c.y * c.y : 0.0, b = live ? c.z * c.z : 0.0;
+                for (int32_t off = stride; off < 64; off <<= 1) {
+                    r += __shfl_xor(r, off); g += __shfl_xor(g, off); b += __shfl_xor(b, off);
+                }
+                if (adds) {
                     double* s = A.sum_sq + 3 * acc_row;
-                    atomicAdd(s, c.x * c.x);
-                    atomicAdd(s + 1, c.y * c.y);
-                    atomicAdd(s + 2, c.z * c.z);
+                    atomicAdd(s, r);
+                    atomicAdd(s + 1, g);
+                    atomicAdd(s + 2, b);
                 }
             }
         }
@@ -293,6 +313,11 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, LaunchArg
                 S.n_lights == 1 && !A.out.rgb && !A.out.rgb8 && !A.out.hit_object && !A.out.hit_prim && !A.out.hit_t &&
                 !A.out.n_rays;
 #endif
+#ifdef RT_ONLY_HOT
+    // experiment builds (tools/variant_bench.sh): only the whole-frame kernel of the benchmark scene
+    if (area_only && !count && !executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
+    else return fail(RTAMD_EUNSUPPORTED, "this build holds the whole-frame area-light kernel only%s");
+#else
     if (extended) {
         if (count) hipLaunchKernelGGL((trace_kernel<MODE, 1, true, true>), grid, block, 0, st, S, A);
         else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, true, true>), grid, block, 0, st, S, A);
@@ -308,6 +333,7 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, LaunchArg
         else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, false, false>), grid, block, 0, st, S, A);
         else hipLaunchKernelGGL((trace_kernel<MODE, 0, false, false>), grid, block, 0, st, S, A);
     }
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return RTAMD_OK;
