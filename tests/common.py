@@ -90,3 +90,26 @@ def compare_with_golden(name, out, ids_exact=True):
         near_integer = numpy.abs(scaled - numpy.rint(scaled)) < 1e-6 * numpy.maximum(1.0, numpy.abs(scaled))
         assert d.max() <= 1 and near_integer[d > 0].all(), "%s: quantised colours differ" % name
     return worst
+
+
+def knife_edge_budget(rgb, n_tiles, n_samples):
+    """Per pixel and channel, how many of its samples have c*255 within rounding of an integer.
+    `rgb` is the oracle's per-sample radiance in (tile, sample, pixel-in-tile) order.  Only
+    such a sample's int(c*255) may differ by one between two float64 evaluations of the same
+    path (ambient-only pixels: 0.2*255 = 51.0 +- 1 ulp), so a pixel's integer sum may differ
+    by at most this number and must be identical where it is zero."""
+    scaled = numpy.asarray(rgb, dtype=numpy.float64) * 255
+    with numpy.errstate(invalid="ignore"):
+        edge = numpy.abs(scaled - numpy.rint(scaled)) < 1e-6 * numpy.maximum(1.0, numpy.abs(scaled))
+    return edge.reshape(n_tiles, n_samples, 64, 3).sum(axis=1).reshape(-1, 3)
+
+
+def assert_integer_sums_match(got_sum, want_sum, want_rgb, n_tiles, n_samples, what=""):
+    """Integer accumulators against the oracle's under the knife-edge rule; returns the number
+    of entries that differ (all of them on knife edges)."""
+    d = numpy.abs(numpy.asarray(got_sum, dtype=numpy.int64) - numpy.asarray(want_sum, dtype=numpy.int64))
+    budget = knife_edge_budget(want_rgb, n_tiles, n_samples)
+    bad = d > budget
+    assert not bad.any(), "%s: %d accumulator entries differ beyond rounding knife-edges (worst by %d)" % (
+        what, int(bad.sum()), int((d - budget).max()))
+    return int((d > 0).sum())

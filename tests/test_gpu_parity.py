@@ -150,8 +150,17 @@ def test_camera_render_matches_reference(torch_gpu):
     world.camera.render(world, lambda coord, r, g_, b: got.append((coord[0], coord[1], r, g_, b)))
     got = numpy.array(got, dtype=numpy.int64)
     assert numpy.array_equal(got[:, :2], g[:, :2])                   # row-major pixel order
+    # mean(c^2)*255 is truncated: a triple may differ by one from the reference's only where
+    # that product sits within rounding of an integer (the CPU checker supplies the float)
+    from raytracer_amd import flatten, runtime
+    from oracle import oracle
+    cam = flatten.camera_record(world)
+    _, want_sq, _ = oracle.OracleScene(flatten.flatten_world(world)).render_tiles(
+        cam, world.seed, numpy.arange(1, dtype=numpy.int32), 0, 4, threads=1)
+    scaled = runtime.scatter_tiles(want_sq, numpy.arange(1), 8, 6).reshape(-1, 3) / 4.0 * 255
+    near_integer = numpy.abs(scaled - numpy.rint(scaled)) < 1e-6 * numpy.maximum(1.0, numpy.abs(scaled))
     d = numpy.abs(got[:, 2:] - g[:, 2:])
-    assert d.max() <= 1 and (d > 0).mean() < 0.02
+    assert d.max() <= 1 and near_integer[d > 0].all()
     prog = []
     world.camera.render_progressive(world, lambda coord, r, g_, b: prog.append((coord[0], coord[1], r, g_, b)))
     prog = numpy.array(prog, dtype=numpy.int64)
@@ -209,10 +218,20 @@ def test_partial_tiles_and_determinism(torch_gpu):
     cam = flatten.camera_record(world)
     tx, ty = runtime.tile_grid(44, 30)
     tiles = numpy.arange(tx * ty, dtype=numpy.int32)
-    want, _, _ = oracle.OracleScene(flatten.flatten_world(world)).render_tiles(cam, world.seed, tiles, 0, 4, threads=8)
-    img = numpy.minimum(runtime.scatter_tiles(want, tiles, 44, 30) / 4.0, 255)
-    d = numpy.abs(a.astype(int) - numpy.clip(img, 0, 255).astype(numpy.uint8).astype(int))
-    assert d.max() <= 1 and (d > 0).mean() < 0.01
+    want, _, per = oracle.OracleScene(flatten.flatten_world(world)).render_tiles(
+        cam, world.seed, tiles, 0, 4, per_sample_want=("rgb",), threads=8)
+    ds = runtime.device_scene(world)
+    fb = runtime.FrameBuffers(ds, tiles)
+    ds.render_tiles(cam, world.seed, fb.tile_ids, 0, 4, sum_rgb8=fb.sum_rgb8)
+    torch_gpu.cuda.synchronize()
+    got = fb.sum_rgb8.cpu().numpy()
+    common.assert_integer_sums_match(got, want, per["rgb"], len(tiles), 4, "44x30 frame")
+    # the image World.render returns is those sums averaged and clamped (main.py:99-106)
+    img = numpy.minimum(runtime.scatter_tiles(got, tiles, 44, 30) / 4.0, 255)
+    assert numpy.array_equal(a, numpy.clip(img, 0, 255).astype(numpy.uint8))
+    # rows of pixels outside the frame stay untouched
+    outside = runtime.scatter_tiles(numpy.ones_like(got), tiles, 44, 30).sum() // 3
+    assert outside == 44 * 30 and got.sum() == runtime.scatter_tiles(got, tiles, 44, 30).sum()
     # seeds matter, and only through the draws
     world2 = _tiny_world("cornellbox_area", resolution=(44, 30), sample_dim=2, seed=10)
     assert not numpy.array_equal(world2.render(mode="parallel"), a)
@@ -336,13 +355,12 @@ def test_full_size_bench_frame_properties(torch_gpu):
     assert numpy.array_equal(total, img)
     # random whole tiles against the oracle
     pick = numpy.sort(numpy.random.RandomState(3).choice(tx * ty, size=96, replace=False)).astype(numpy.int32)
-    want, _, _ = oracle.OracleScene(ds.flat).render_tiles(cam, world.seed, pick, 0, n_samples, threads=8)
-    got = runtime.scatter_tiles(whole.sum_rgb8.cpu().numpy(), tiles, cam.width, cam.height)
-    want_img = runtime.scatter_tiles(want, pick, cam.width, cam.height)
-    mask = runtime.scatter_tiles(numpy.ones_like(want), pick, cam.width, cam.height) > 0
-    d = numpy.abs(got[mask] - want_img[mask])
-    # a sample's int(c*255) may differ by one where c*255 sits within rounding of an integer
-    assert d.max() <= n_samples and (d > 0).mean() < 0.02
+    want, _, per = oracle.OracleScene(ds.flat).render_tiles(cam, world.seed, pick, 0, n_samples,
+                                                            per_sample_want=("rgb",), threads=8)
+    # tiles are listed in ascending order, so the whole frame's rows of tile t start at 64*t
+    got = whole.sum_rgb8.cpu().numpy().reshape(-1, 64, 3)[pick].reshape(-1, 3)
+    differing = common.assert_integer_sums_match(got, want, per["rgb"], len(pick), n_samples, "bench frame")
+    print("bench frame vs oracle on %d tiles: %d knife-edge entries" % (len(pick), differing))
 
 
 def test_kd_shortcuts_from_other_viewpoints(torch_gpu):
@@ -479,7 +497,6 @@ def test_two_tree_objects_under_the_area_tracer(torch_gpu):
     work = ds.read_counters(reset=True)
     assert torch.equal(timed.sum_rgb8, counted.sum_rgb8)
     osc = oracle.OracleScene(ds.flat)
-    want, _, _ = osc.render_tiles(cam, world.seed, tiles, 0, 4, threads=8)
+    want, _, per = osc.render_tiles(cam, world.seed, tiles, 0, 4, per_sample_want=("rgb",), threads=8)
     assert work == osc.read_counters(reset=True)
-    d = numpy.abs(counted.sum_rgb8.cpu().numpy() - want)
-    assert d.max() <= 4 and (d > 0).mean() < 0.02
+    common.assert_integer_sums_match(counted.sum_rgb8.cpu().numpy(), want, per["rgb"], len(tiles), 4, "two trees")
