@@ -1372,20 +1372,23 @@ __device__ __forceinline__ V3 hemisphere_about(V3 w, V3 sp) {
     return (u * sp.x + v * sp.y) + w * sp.z;
 }
 
-// pow() as a call of its own in experiment builds: inlined, its polynomial constants are hoisted
-// in front of the bounce loop and carried (spilled) through it.
-#ifdef RT_POW_CALL
-__device__ __attribute__((noinline)) double rt_pow(double a, double b) { return pow(a, b); }
-#else
-__device__ __forceinline__ double rt_pow(double a, double b) { return pow(a, b); }
-#endif
+// pow() inlined into a kernel with a bounce loop has its polynomial constants hoisted in front of
+// the loop and carried - spilled and reloaded one by one - through it.  The kernels for scenes
+// without a kd-tree therefore call it as a function (mirror hall 4K frame: 125 -> 106 ms,
+// foursphere 0.18 -> 0.14 ms); in the kd kernels the call's own register conventions cost more
+// than they save (dragon frame 11.46 -> 11.73 ms), so those inline it.
+__device__ __attribute__((noinline)) double pow_as_call(double a, double b) { return pow(a, b); }
+template <bool CALL> __device__ __forceinline__ double rt_pow(double a, double b) {
+    return CALL ? pow_as_call(a, b) : pow(a, b);
+}
 
 // GlossySpecular.f (material.py:88-97) with ks*cs folded into `spec`.
+template <bool POW_CALL>
 __device__ __forceinline__ V3 phong_lobe(V3 spec, double exp_, V3 n, V3 wo, V3 wi) {
     const double ndotwi = dot(n, wi);
     const V3 r = (-wi) + (2.0 * n) * ndotwi;
     const double rdotwo = dot(r, wo);
-    if (rdotwo > 0.0) return spec * rt_pow(rdotwo, exp_);
+    if (rdotwo > 0.0) return spec * rt_pow<POW_CALL>(rdotwo, exp_);
     return v3(0, 0, 0);
 }
 
@@ -1480,10 +1483,10 @@ __device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, b
         auto light_term = [&]() {
             V3 f = ld3(m.diffuse);
             if (textured) f = (f * tex) / PI;                                                    // material.py:27-28
-            if (phong) f = f + phong_lobe(ld3(m.specular), m.exp, h.n, wo, wi);
+            if (phong) f = f + phong_lobe<!TREES>(ld3(m.specular), m.exp, h.n, wo, wi);
             V3 Ll = ld3(lt.radiance);
             if (lt.kind == RTAMD_POINT && lt.attenuation != 0)                                    // light.py:39-44
-                Ll = Ll * rt_pow(norm(h.p - ld3(lt.position)) / lt.radius, -lt.attenuation);
+                Ll = Ll * rt_pow<!TREES>(norm(h.p - ld3(lt.position)) / lt.radius, -lt.attenuation);
             if (lt.kind == RTAMD_AREA && !(dot(ld3(lt.normal), wi) < 0.)) Ll = v3(0, 0, 0);        // light.py:110-114
             term = (f * Ll) * ndotwi;
             if (area) {
@@ -1543,7 +1546,7 @@ __device__ __forceinline__ bool refraction(const rtamd_material& m, V3 n, V3 d, 
     return temp < 0.;
 }
 
-__device__ __forceinline__ V3 powv(V3 b, double e) { return v3(rt_pow(b.x, e), rt_pow(b.y, e), rt_pow(b.z, e)); }
+__device__ __forceinline__ V3 powv(V3 b, double e) { return v3(rt_pow<false>(b.x, e), rt_pow<false>(b.y, e), rt_pow<false>(b.z, e)); }
 
 // tracer.trace_ray (tracer.py:26-35, :43-58, :65-71, :79-88) for the 64 samples of a wave.
 // The single-child recursion of Reflective / GlossyReflective / Matte.path_shade
@@ -1659,7 +1662,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
             const V3 sp = draw_hemisphere(S, m.sampler, dr);
             V3 wi = (sp.x * u + sp.y * v) + sp.z * wr;
             if (dot(h.n, wi) < 0.0) wi = ((-sp.x) * u - sp.y * v) + sp.z * wr;
-            const double lobe = rt_pow(dot(wr, wi), m.reflect_exp);
+            const double lobe = rt_pow<!TREES>(dot(wr, wi), m.reflect_exp);
             double pdf = lobe * dot(h.n, wi);
             V3 fr;
             if (pdf == 0) { fr = v3(0, 0, 0); pdf = 1; }
