@@ -32,6 +32,10 @@ enum { MODE_PIXELS = 0, MODE_RAYS = 1, MODE_TILES = 2 };
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
+#ifndef RT_MIN_WAVES_ANALYTIC
+// waves per SIMD the kernels for scenes without a kd-tree are held to (they need no traversal state)
+#define RT_MIN_WAVES_ANALYTIC 4
+#endif
 #ifndef RT_GROUP_SHIFT_MAX
 // Tile mode: a wave takes up to 2^RT_GROUP_SHIFT_MAX samples of each of its pixels (see the
 // kernel).  1080p dragon frame, 16 samples per pixel: 8x8 pixels x 1 sample 16.41 ms,
@@ -118,7 +122,7 @@ __device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point,
 // TREES = false instantiations serve scenes without a kd-tree (analytic primitives only):
 // no traversal code, no LDS stack, and the registers go to the shading loop.
 template <int MODE, int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
-__global__ __launch_bounds__(BLOCK, RT_MIN_WAVES) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
+__global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
     // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
     // work list is cut into RT_XCD_SEGMENTS contiguous segments and segment j is given to
