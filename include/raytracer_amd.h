@@ -24,6 +24,7 @@
 #ifndef RAYTRACER_AMD_H
 #define RAYTRACER_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -389,6 +390,43 @@ int rtamd_render_tiles(rtamd_scene *scene, const rtamd_camera *camera, uint64_t 
                        const rtamd_sample_out *per_sample,
                        int64_t *sum_rgb8, double *sum_sq,
                        uint64_t *counters, uint32_t flags, void *stream);
+
+/* ---- device-side kd-tree build ------------------------------------------------------
+ * KDTree(BoundingBoxes(boxes))  (kdtree.py:8-24, :27-52, :56-69, :92-131): builds, on the
+ * device, exactly the tree the reference's recursion builds from n axis-aligned boxes
+ * (box_lo[n][3], box_hi[n][3], device, in the order of the list given to BoundingBoxes).
+ * The tree comes back in preorder (the left child of node i is node i+1):
+ *   axis[i]   0/1/2 for an interior node (KDTree.split_idx), -1 for a leaf
+ *   split[i]  KDTree.split_center of an interior node
+ *   left[i], right[i]   child node indices (-1 for a leaf)
+ *   first[i], count[i]  a leaf's slice of leaf_refs (0, 0 for an interior node)
+ *   leaf_refs           box indices, every leaf's list in the order KDTree.hit scans it
+ * All output arrays are device memory owned by the caller, max_nodes / max_refs entries long.
+ * The call is synchronous on `stream` (it reads a few totals back after every tree level). */
+typedef struct rtamd_kd_tree_out {
+    int32_t *axis;
+    double *split;
+    int32_t *left, *right, *first, *count;
+    int32_t *leaf_refs;
+    int64_t max_nodes, max_refs;
+} rtamd_kd_tree_out;
+
+/* Bytes of device workspace rtamd_kd_build needs when no tree level holds more than
+ * level_capacity box references (straddling boxes are referenced by both children,
+ * kdtree.py:52; 4 * n_boxes has been enough for every mesh of the reference). */
+int rtamd_kd_build_workspace_bytes(int64_t level_capacity, int64_t max_nodes, int64_t max_refs,
+                                   size_t *bytes);
+
+/* Fails with RTAMD_EUNSUPPORTED (and leaves the outputs undefined) when a level outgrows
+ * level_capacity or the tree outgrows max_nodes / max_refs.  n_nodes, n_refs and depth
+ * (maximum node depth, root = 0) are host pointers. */
+int rtamd_kd_build(const double *box_lo, const double *box_hi, int64_t n_boxes,
+                   const rtamd_kd_tree_out *out, void *workspace, size_t workspace_bytes,
+                   int64_t level_capacity, int64_t *n_nodes, int64_t *n_refs, int32_t *depth,
+                   void *stream);
+
+/* Message of the calling thread's last failed rtamd_kd_* call. */
+const char *rtamd_kd_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -19,12 +19,21 @@ is restated on those arrays:
 
 Traversal and leaf tests run on the GPU (csrc/rt_device.h); `hit`/`shadow_hit`
 are not methods of this class.
+
+The same build also exists on the device (csrc/rt_kdbuild.hip, `rtamd_kd_build`): level by
+level, the same stable sorts and the same arithmetic, yielding the same arrays.  `KD_BUILD`
+(environment variable RTAMD_KD_BUILD) picks the builder: "host", "device", or "auto" - the
+device for lists of at least `DEVICE_BUILD_MIN_BOXES` boxes when a GPU is visible.
 """
+import os
+
 import numpy
 
 from geometry import BoundingBox, GeometryObject, INF, epsilon
 
 LEAF_LIMIT = 20          # kdtree.py:94
+KD_BUILD = os.environ.get("RTAMD_KD_BUILD", "auto")
+DEVICE_BUILD_MIN_BOXES = 2000
 
 
 class BoundingBoxes(object):
@@ -110,6 +119,11 @@ class KDTree(GeometryObject):
         if max_d is None:
             max_d = [bb.x1, bb.y1, bb.z1]
         self._lo, self._hi = bounding_boxes.lo, bounding_boxes.hi
+        self.built_on = "host"
+        if not leaf and self._wants_device(len(bounding_boxes.boxes)) and \
+                [float(v) for v in min_d] == [bb.x0, bb.y0, bb.z0] and [float(v) for v in max_d] == [bb.x1, bb.y1, bb.z1]:
+            self._build_on_device()
+            return
         self._axis, self._split = [], []
         self._left, self._right = [], []
         self._first, self._count = [], []
@@ -129,6 +143,65 @@ class KDTree(GeometryObject):
         del self._axis, self._split, self._left, self._right, self._first, self._count, self._refs
 
     # -- build -----------------------------------------------------------------------
+    @staticmethod
+    def _wants_device(n_boxes):
+        if KD_BUILD == "host" or n_boxes < 1:
+            return False
+        if KD_BUILD == "device":
+            return True
+        if n_boxes < DEVICE_BUILD_MIN_BOXES:
+            return False
+        try:
+            import torch
+            return torch.cuda.is_available()
+        except ImportError:
+            return False
+
+    def _build_on_device(self, level_factor=4):
+        """The same tree from `rtamd_kd_build`.  Levels may hold up to `level_factor` times
+        the box count (boxes that straddle a plane go to both children); when a mesh needs
+        more, the build is repeated with a larger workspace."""
+        import ctypes as C
+        import torch
+        from raytracer_amd import capi
+        lib = capi.library()
+        n = len(self._lo)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        lo = torch.from_numpy(numpy.ascontiguousarray(self._lo)).to(dev)
+        hi = torch.from_numpy(numpy.ascontiguousarray(self._hi)).to(dev)
+        while True:
+            cap_items = max(level_factor * n, 1024)
+            max_nodes, max_refs = 2 * cap_items, 2 * cap_items
+            i32 = dict(dtype=torch.int32, device=dev)
+            arrays = dict(axis=torch.empty(max_nodes, **i32), split=torch.empty(max_nodes, dtype=torch.float64, device=dev),
+                          left=torch.empty(max_nodes, **i32), right=torch.empty(max_nodes, **i32),
+                          first=torch.empty(max_nodes, **i32), count=torch.empty(max_nodes, **i32),
+                          leaf_refs=torch.empty(max_refs, **i32))
+            out = capi.KdTreeOut(max_nodes=max_nodes, max_refs=max_refs, **{k: v.data_ptr() for k, v in arrays.items()})
+            need = C.c_size_t()
+            capi.check_kd(lib.rtamd_kd_build_workspace_bytes(cap_items, max_nodes, max_refs, C.byref(need)), lib)
+            workspace = torch.empty(need.value, dtype=torch.uint8, device=dev)
+            n_nodes, n_refs, depth = C.c_int64(), C.c_int64(), C.c_int32()
+            torch.cuda.current_stream(dev).synchronize()
+            rc = lib.rtamd_kd_build(lo.data_ptr(), hi.data_ptr(), n, C.byref(out), workspace.data_ptr(), need.value,
+                                    cap_items, C.byref(n_nodes), C.byref(n_refs), C.byref(depth),
+                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if rc == capi.EUNSUPPORTED and level_factor < 64:
+                level_factor *= 2           # a level (or the tree) outgrew the buffers
+                continue
+            capi.check_kd(rc, lib)
+            break
+        nn, nr = n_nodes.value, n_refs.value
+        self.axis = arrays["axis"][:nn].cpu().numpy()
+        self.split = arrays["split"][:nn].cpu().numpy()
+        self.left = arrays["left"][:nn].cpu().numpy()
+        self.right = arrays["right"][:nn].cpu().numpy()
+        self.first = arrays["first"][:nn].cpu().numpy()
+        self.count = arrays["count"][:nn].cpu().numpy()
+        self.leaf_refs = arrays["leaf_refs"][:nr].cpu().numpy()
+        self.depth = int(depth.value)
+        self.built_on = "device"
+
     def _new_node(self):
         for arr, v in ((self._axis, -1), (self._split, 0.0), (self._left, -1),
                        (self._right, -1), (self._first, 0), (self._count, 0)):

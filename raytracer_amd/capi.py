@@ -103,7 +103,14 @@ class SampleOut(C.Structure):
 #: every symbol include/raytracer_amd.h declares
 EXPORTS = ("rtamd_abi_version", "rtamd_device_check", "rtamd_last_error",
            "rtamd_scene_create", "rtamd_scene_destroy", "rtamd_render_pixels",
-           "rtamd_trace_rays", "rtamd_render_tiles")
+           "rtamd_trace_rays", "rtamd_render_tiles",
+           "rtamd_kd_build_workspace_bytes", "rtamd_kd_build", "rtamd_kd_last_error")
+
+
+class KdTreeOut(C.Structure):
+    _fields_ = [("axis", C.c_void_p), ("split", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p),
+                ("first", C.c_void_p), ("count", C.c_void_p), ("leaf_refs", C.c_void_p),
+                ("max_nodes", C.c_int64), ("max_refs", C.c_int64)]
 
 
 def bind(lib):
@@ -129,6 +136,13 @@ def bind(lib):
     lib.rtamd_render_tiles.restype = C.c_int
     lib.rtamd_render_tiles.argtypes = [vp, C.POINTER(Camera), u64, i64, vp, i32, i32,
                                        C.POINTER(SampleOut), vp, vp, vp, u32, vp]
+    lib.rtamd_kd_build_workspace_bytes.restype = C.c_int
+    lib.rtamd_kd_build_workspace_bytes.argtypes = [i64, i64, i64, C.POINTER(C.c_size_t)]
+    lib.rtamd_kd_build.restype = C.c_int
+    lib.rtamd_kd_build.argtypes = [vp, vp, i64, C.POINTER(KdTreeOut), vp, C.c_size_t, i64,
+                                   C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), vp]
+    lib.rtamd_kd_last_error.restype = C.c_char_p
+    lib.rtamd_kd_last_error.argtypes = []
     return lib
 
 
@@ -147,6 +161,15 @@ def library():
         if _lib.rtamd_abi_version() != ABI_VERSION:
             raise RuntimeError("librtamd.so ABI %d != binding ABI %d" % (_lib.rtamd_abi_version(), ABI_VERSION))
     return _lib
+
+
+EUNSUPPORTED = -2
+
+
+def check_kd(status, lib=None):
+    if status != 0:
+        lib = lib or library()
+        raise RuntimeError("rtamd_kd_build failed (%d): %s" % (status, lib.rtamd_kd_last_error().decode()))
 
 
 def check(status, lib=None):
