@@ -425,6 +425,19 @@ int rtamd_kd_build(const double *box_lo, const double *box_hi, int64_t n_boxes,
                    int64_t level_capacity, int64_t *n_nodes, int64_t *n_refs, int32_t *depth,
                    void *stream);
 
+/* The same build without a workspace argument and without any allocation.  It has no
+ * counterpart in the reference; it exists for callers that cannot allocate device memory
+ * (code under HIP graph capture set-up, serving loops and harnesses that forbid hipMalloc).
+ * The buffers live in a static array of the library's code object (11 MiB, held by every GPU
+ * the library runs on until the process ends), which limits it to n_boxes <= 8192, 24576
+ * references per tree level, 32768 nodes and 32768 leaf references; larger inputs fail with
+ * RTAMD_EUNSUPPORTED and a message that names the limit.  All calls on one GPU share that
+ * array: calls that overlap in time on the same GPU race and must be serialised by the caller.
+ * Inputs, outputs and results are as for rtamd_kd_build. */
+int rtamd_kd_build_static(const double *box_lo, const double *box_hi, int64_t n_boxes,
+                          const rtamd_kd_tree_out *out, int64_t *n_nodes, int64_t *n_refs,
+                          int32_t *depth, void *stream);
+
 /* Message of the calling thread's last failed rtamd_kd_* call. */
 const char *rtamd_kd_last_error(void);
 

@@ -104,7 +104,7 @@ class SampleOut(C.Structure):
 EXPORTS = ("rtamd_abi_version", "rtamd_device_check", "rtamd_last_error",
            "rtamd_scene_create", "rtamd_scene_destroy", "rtamd_render_pixels",
            "rtamd_trace_rays", "rtamd_render_tiles",
-           "rtamd_kd_build_workspace_bytes", "rtamd_kd_build", "rtamd_kd_last_error")
+           "rtamd_kd_build_workspace_bytes", "rtamd_kd_build", "rtamd_kd_build_static", "rtamd_kd_last_error")
 
 
 class KdTreeOut(C.Structure):
@@ -141,6 +141,9 @@ def bind(lib):
     lib.rtamd_kd_build.restype = C.c_int
     lib.rtamd_kd_build.argtypes = [vp, vp, i64, C.POINTER(KdTreeOut), vp, C.c_size_t, i64,
                                    C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), vp]
+    lib.rtamd_kd_build_static.restype = C.c_int
+    lib.rtamd_kd_build_static.argtypes = [vp, vp, i64, C.POINTER(KdTreeOut), C.POINTER(i64), C.POINTER(i64),
+                                          C.POINTER(i32), vp]
     lib.rtamd_kd_last_error.restype = C.c_char_p
     lib.rtamd_kd_last_error.argtypes = []
     return lib

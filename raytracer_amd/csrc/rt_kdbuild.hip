@@ -25,6 +25,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/raytracer_amd.h"
 
@@ -528,11 +529,64 @@ int check_args(const double* lo, const double* hi, int64_t n, const rtamd_kd_tre
     return RTAMD_OK;
 }
 
+// ------------------------------------------------------------------ the workspace that needs no allocation
+// rtamd_kd_build_static keeps the build's buffers in this array of the code object instead of a
+// workspace from the caller.  Every GPU the library runs on holds its own copy at its own
+// address; the array's name is only a host-side handle, so the address is asked for once per
+// device (hipGetSymbolAddress with that device current) and used from then on.
+constexpr int64_t STATIC_MAX_BOXES = 8192;
+constexpr int64_t STATIC_LEVEL_CAPACITY = 3 * STATIC_MAX_BOXES;     // references one tree level may hold
+constexpr int64_t STATIC_MAX_NODES = 32768;
+constexpr int64_t STATIC_MAX_REFS = 32768;
+constexpr size_t STATIC_BYTES = 11 * 1024 * 1024;
+static __device__ __align__(256) unsigned char scratch[STATIC_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES];
+bool g_scratch_known[MAX_DEVICES];
+std::mutex g_scratch_lock;
+
+int static_scratch(void** ptr) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return kd_hip(e, "hipGetDevice");
+    if (dev < 0 || dev >= MAX_DEVICES) return kd_fail(RTAMD_EUNSUPPORTED, "kd build: device index beyond the table of static workspaces");
+    std::lock_guard<std::mutex> guard(g_scratch_lock);
+    if (!g_scratch_known[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return kd_hip(e, "address of the static kd workspace");
+        g_scratch_ptr[dev] = p;
+        g_scratch_known[dev] = true;
+    }
+    *ptr = g_scratch_ptr[dev];
+    return RTAMD_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* rtamd_kd_last_error(void) { return g_kd_error; }
+
+int rtamd_kd_build_static(const double* box_lo, const double* box_hi, int64_t n_boxes, const rtamd_kd_tree_out* out,
+                          int64_t* n_nodes, int64_t* n_refs, int32_t* depth, void* stream) {
+    int rc = check_args(box_lo, box_hi, n_boxes, out, n_nodes, n_refs, depth);
+    if (rc) return rc;
+    if (n_boxes > STATIC_MAX_BOXES)
+        return kd_fail(RTAMD_EUNSUPPORTED, "rtamd_kd_build_static handles at most 8192 boxes; larger lists need rtamd_kd_build with a workspace");
+    void* ws = nullptr;
+    rc = static_scratch(&ws);
+    if (rc) return rc;
+    Build B;
+    memset(&B, 0, sizeof(B));
+    B.box_lo = box_lo; B.box_hi = box_hi; B.n_boxes = n_boxes;
+    B.cap_items = STATIC_LEVEL_CAPACITY; B.cap_nodes = STATIC_MAX_NODES; B.cap_refs = STATIC_MAX_REFS;
+    Carver c = {static_cast<char*>(ws), 0, STATIC_BYTES};
+    carve(B, c);
+    if (c.used > STATIC_BYTES) return kd_fail(RTAMD_EUNSUPPORTED, "kd build: static workspace smaller than its layout");
+    return build_tree(B, out, n_nodes, n_refs, depth, static_cast<hipStream_t>(stream));
+}
 
 int rtamd_kd_build_workspace_bytes(int64_t level_capacity, int64_t max_nodes, int64_t max_refs, size_t* bytes) {
     if (!bytes || level_capacity < 1 || max_nodes < 1 || max_refs < 1) return kd_fail(RTAMD_EINVAL, "kd workspace: bad argument");
