@@ -115,6 +115,37 @@ __device__ __forceinline__ Ray camera_ray(const rtamd_camera& c, V3 plane_point,
     return r;
 }
 
+// Tile mode: the camera ray of sample k (camera.py:78 (+ :246): one pattern choice per pixel, plus an
+// independent disk pattern for a thin lens; camera.py:90-93: the view-plane point).  Returns false
+// for samples of pixels outside the image.
+__device__ __forceinline__ bool tile_ray(const rtamd_scene_desc& S, const LaunchArgs& A, int64_t k, Ray& ray,
+                                         int32_t& pixel, int32_t& sample, int64_t& acc_row, int64_t& ko) {
+    const TileSlot ts = tile_slot(A, k);
+    const int32_t col = ts.col, row = ts.row, soff = ts.soff;
+    if (col >= A.cam.width || row >= A.cam.height) return false;
+    pixel = row * A.cam.width + col;
+    sample = A.sample_begin + soff;
+    acc_row = ts.acc_row;
+    ko = ts.ko;
+    const rtamd_sampler sm = S.samplers[A.cam.sampler];
+    Draw pd;
+    pd.key = mix64(A.pixel_key ^ (uint64_t)(uint32_t)pixel);
+    pd.sample = 0;
+    pd.counter = 0;
+    const uint32_t pat = sm.regular ? 0u : pd.index((uint32_t)sm.num_patterns);
+    const double* sq = S.sampler_data + sm.square_offset + 2 * ((int64_t)pat * sm.samples_per_pattern + sample);
+    const V3 pp = v3(A.cam.pixel_size * (col - A.cam.width / 2 + sq[0]),
+                     A.cam.pixel_size * (row - A.cam.height / 2 + sq[1]), 0.0);
+    V3 lens = v3(0, 0, 0);
+    if (A.cam.thin_lens) {
+        const uint32_t dpat = sm.regular ? 0u : pd.index((uint32_t)sm.num_patterns);
+        const double* dk = S.sampler_data + sm.disk_offset + 2 * ((int64_t)dpat * sm.samples_per_pattern + sample);
+        lens = ld3(A.cam.eye) + v3(dk[0], dk[1], 0.0) * A.cam.lens_radius;   // camera.py:262
+    }
+    ray = camera_ray(A.cam, pp, lens);
+    return true;
+}
+
 // EXT instantiations serve scenes with two-child materials (Transparent, Dielectric) or
 // textured ones (SV_Matte); they keep a per-lane list of waiting child rays in private
 // memory and a texture colour across the shadow queries, which the other instantiations
@@ -159,34 +190,7 @@ __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC
             const V3 lens = A.cam.thin_lens ? ld3(A.b3 + 3 * k) : v3(0, 0, 0);
             ray = camera_ray(A.cam, ld3(A.a3 + 3 * k), lens);
         } else {
-            const TileSlot ts = tile_slot(A, k);
-            const int32_t col = ts.col, row = ts.row, soff = ts.soff;
-            if (col >= A.cam.width || row >= A.cam.height) {
-                live = false;
-            } else {
-                pixel = row * A.cam.width + col;
-                sample = A.sample_begin + soff;
-                acc_row = ts.acc_row;
-                ko = ts.ko;
-                // camera.py:78 (+ :246): one pattern choice per pixel, plus an independent
-                // disk pattern for a thin lens; camera.py:90-93: the view-plane point.
-                const rtamd_sampler sm = S.samplers[A.cam.sampler];
-                Draw pd;
-                pd.key = mix64(A.pixel_key ^ (uint64_t)(uint32_t)pixel);
-                pd.sample = 0;
-                pd.counter = 0;
-                const uint32_t pat = sm.regular ? 0u : pd.index((uint32_t)sm.num_patterns);
-                const double* sq = S.sampler_data + sm.square_offset + 2 * ((int64_t)pat * sm.samples_per_pattern + sample);
-                const V3 pp = v3(A.cam.pixel_size * (col - A.cam.width / 2 + sq[0]),
-                                 A.cam.pixel_size * (row - A.cam.height / 2 + sq[1]), 0.0);
-                V3 lens = v3(0, 0, 0);
-                if (A.cam.thin_lens) {
-                    const uint32_t dpat = sm.regular ? 0u : pd.index((uint32_t)sm.num_patterns);
-                    const double* dk = S.sampler_data + sm.disk_offset + 2 * ((int64_t)dpat * sm.samples_per_pattern + sample);
-                    lens = ld3(A.cam.eye) + v3(dk[0], dk[1], 0.0) * A.cam.lens_radius;   // camera.py:262
-                }
-                ray = camera_ray(A.cam, pp, lens);
-            }
+            live = tile_ray(S, A, k, ray, pixel, sample, acc_row, ko);
         }
 
     }
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC
         stk.node = stack_node;
         stk.t = stack_t;
         stk.slot = stack_slot;
-        const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, live, ray, A.depth0, dr, work, first);
+const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, live, ray, A.depth0, dr, work, first);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
             if (!AREA_ONLY) {

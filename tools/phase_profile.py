@@ -25,7 +25,8 @@ NAMES = ["descent", "pack16", "pack32", "big_plain", "big_boxes", "pop", "querie
 def build():
     import __graft_entry__ as entry
     src = os.path.join(REPO, "raytracer_amd", "csrc", "rt_kernels.hip")
-    cmd = ["/opt/rocm/bin/hipcc"] + entry.HIP_FLAGS + ["-DRT_PHASE_TIMERS", "-DRT_ONLY_TILES", "-I", os.path.join(REPO, "include"), src, "-o", LIB]
+    kd = os.path.join(REPO, "raytracer_amd", "csrc", "rt_kdbuild.hip")
+    cmd = ["/opt/rocm/bin/hipcc"] + entry.HIP_FLAGS + ["-DRT_PHASE_TIMERS", "-DRT_ONLY_TILES", "-I", os.path.join(REPO, "include"), src, kd, "-o", LIB]
     subprocess.check_call(cmd)
 
 
