@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "rt_device.h"
 
@@ -399,7 +400,17 @@ int rtamd_device_check(void) {
 
 int rtamd_scene_destroy(rtamd_scene* scene);
 
+static int scene_create(const rtamd_scene_desc* d, rtamd_scene** out);
+
 int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
+    try {
+        return scene_create(d, out);
+    } catch (...) {             // host copies of the small tables are std::vectors
+        return fail(RTAMD_EINVAL, "out of host memory%s");
+    }
+}
+
+static int scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
     if (!d || !out) return fail(RTAMD_EINVAL, "null argument%s");
     if (d->abi_version != RTAMD_ABI_VERSION) return fail(RTAMD_EINVAL, "descriptor ABI version mismatch%s");
     if (d->tracer_kind < RTAMD_TRACER_SHADE || d->tracer_kind > RTAMD_TRACER_WHITTED)
@@ -447,11 +458,14 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
             return fail(RTAMD_EINVAL, "a sampler table lies outside sampler_data%s");
         }
     }
-    // sampler references of materials and lights (small tables: checked on a host copy)
-    for (int i = 0; i < d->n_materials; ++i) {
-        rtamd_material m;
-        e = hipMemcpy(&m, d->materials + i, sizeof(m), hipMemcpyDeviceToHost);
+    // sampler references of materials and lights (small tables: checked on a host copy, one copy per table)
+    std::vector<rtamd_material> materials((size_t)d->n_materials);
+    if (d->n_materials) {
+        e = hipMemcpy(materials.data(), d->materials, sizeof(rtamd_material) * d->n_materials, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the material table"); }
+    }
+    for (int i = 0; i < d->n_materials; ++i) {
+        const rtamd_material& m = materials[i];
         const bool draws = m.kind == RTAMD_GLOSSY_REFLECTIVE || (d->tracer_kind == RTAMD_TRACER_PATH && m.kind == RTAMD_MATTE);
         if (m.kind < RTAMD_MATTE || m.kind > RTAMD_SV_MATTE) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "unknown material kind%s"); }
         if (m.kind == RTAMD_SV_MATTE) {
@@ -494,10 +508,13 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
         rtamd_scene_destroy(s);
         return fail(RTAMD_EINVAL, "texture tables missing%s");
     }
-    for (int i = 0; i < d->n_textures; ++i) {
-        rtamd_texture t;
-        e = hipMemcpy(&t, d->textures + i, sizeof(t), hipMemcpyDeviceToHost);
+    std::vector<rtamd_texture> textures((size_t)d->n_textures);
+    if (d->n_textures) {
+        e = hipMemcpy(textures.data(), d->textures, sizeof(rtamd_texture) * d->n_textures, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the texture table"); }
+    }
+    for (int i = 0; i < d->n_textures; ++i) {
+        const rtamd_texture& t = textures[i];
         if (t.width < 1 || t.height < 1 || t.hres < 1 || t.vres < 1 || t.hres > t.width || t.vres > t.height ||
             t.offset < 0 || t.offset + 3 * (int64_t)t.width * t.height > d->n_texel_bytes) {
             rtamd_scene_destroy(s);
@@ -505,20 +522,26 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
         }
         if (t.mapping != RTAMD_MAP_SPHERICAL) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "unknown texture mapping%s"); }
     }
-    for (int i = 0; i < d->n_lights; ++i) {
-        rtamd_light l;
-        e = hipMemcpy(&l, d->lights + i, sizeof(l), hipMemcpyDeviceToHost);
+    std::vector<rtamd_light> lights((size_t)d->n_lights);
+    if (d->n_lights) {
+        e = hipMemcpy(lights.data(), d->lights, sizeof(rtamd_light) * d->n_lights, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the light table"); }
+    }
+    for (int i = 0; i < d->n_lights; ++i) {
+        const rtamd_light& l = lights[i];
         if (l.kind < RTAMD_POINT || l.kind > RTAMD_ENVIRONMENT) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "unknown light kind%s"); }
         if ((l.kind == RTAMD_AREA || l.kind == RTAMD_ENVIRONMENT) && (l.sampler < 0 || l.sampler >= d->n_samplers)) {
             rtamd_scene_destroy(s);
             return fail(RTAMD_EINVAL, "an area or environment light has no sampler%s");
         }
     }
-    for (int i = 0; i < d->n_objects; ++i) {
-        rtamd_object o;
-        e = hipMemcpy(&o, d->objects + i, sizeof(o), hipMemcpyDeviceToHost);
+    std::vector<rtamd_object> objects((size_t)d->n_objects);
+    if (d->n_objects) {
+        e = hipMemcpy(objects.data(), d->objects, sizeof(rtamd_object) * d->n_objects, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the object table"); }
+    }
+    for (int i = 0; i < d->n_objects; ++i) {
+        const rtamd_object& o = objects[i];
         const bool tree = o.kind == RTAMD_KDTREE;
         if (tree) s->tree_objects++;
         if (o.kind < RTAMD_SPHERE || o.kind > RTAMD_KDTREE || (tree && (o.tree < 0 || o.tree >= d->n_trees)) ||
@@ -528,10 +551,13 @@ int rtamd_scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
             return fail(RTAMD_EINVAL, "an object refers to a tree or material outside its table%s");
         }
     }
-    for (int i = 0; i < d->n_trees; ++i) {
-        rtamd_tree t;
-        e = hipMemcpy(&t, d->trees + i, sizeof(t), hipMemcpyDeviceToHost);
+    std::vector<rtamd_tree> trees((size_t)d->n_trees);
+    if (d->n_trees) {
+        e = hipMemcpy(trees.data(), d->trees, sizeof(rtamd_tree) * d->n_trees, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rtamd_scene_destroy(s); return hip_fail(e, "reading the tree table"); }
+    }
+    for (int i = 0; i < d->n_trees; ++i) {
+        const rtamd_tree& t = trees[i];
         if (t.depth + 2 > STACK_MAX) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "kd-tree deeper than the traversal stack%s"); }
         if (t.node_offset < 0 || t.node_offset >= d->n_kd_nodes) { rtamd_scene_destroy(s); return fail(RTAMD_EINVAL, "tree root outside kd_nodes%s"); }
         if (t.depth > s->max_tree_depth) s->max_tree_depth = t.depth;
