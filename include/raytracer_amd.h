@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 4
+#define RTAMD_ABI_VERSION 5
 
 enum {
     RTAMD_OK = 0,
@@ -93,7 +93,10 @@ enum {
  *   KDTREE     -  (see `tree`)
  * With has_transform the object is an Instance (geometry.py:85-112): `inv_point` is the
  * upper 3x4 of inverse(M) row-major, `inv_dir` is inverse(M[:3,:3]) row-major (the
- * reference inverts the two separately). */
+ * reference inverts the two separately).  An Instance may wrap another Instance: `inv_point` /
+ * `inv_dir` then belong to the outermost one and the n_inner further levels, from the outside
+ * in, are transforms[inner_offset .. inner_offset + n_inner); a ray passes through them in that
+ * order, a normal comes back through them in the opposite one. */
 typedef struct rtamd_object {
     int32_t kind;
     int32_t material;       /* index into materials; -1 for KDTREE                */
@@ -102,12 +105,20 @@ typedef struct rtamd_object {
     int32_t has_transform;
     int32_t tree;           /* index into trees for KDTREE, else -1               */
     int32_t smooth;         /* TRIANGLE: vertex normals present                   */
-    int32_t reserved;
+    int32_t n_inner;        /* Instance levels inside the outermost one (usually 0) */
     double p[30];
     double inv_point[12];
     double inv_dir[9];
-    double pad_;            /* keeps sizeof a multiple of 16                       */
+    int32_t inner_offset;   /* first of the n_inner entries in transforms          */
+    int32_t pad_;           /* keeps sizeof a multiple of 16                       */
 } rtamd_object;
+
+/* One inner level of a nested Instance (see rtamd_object). */
+typedef struct rtamd_transform {
+    double inv_point[12];
+    double inv_dir[9];
+    double pad_[3];
+} rtamd_transform;
 
 typedef struct rtamd_material {
     int32_t kind;
@@ -272,7 +283,7 @@ typedef struct rtamd_scene_desc {
     const int64_t *prim_normal_offset;  /* device */
     const int32_t *prim_material;       /* device */
     int32_t n_textures;
-    int32_t reserved;
+    int32_t n_transforms;
     int64_t n_texel_bytes;
     const rtamd_texture *textures;      /* device, NULL when n_textures == 0 */
     const uint8_t *texels;              /* device */
@@ -289,6 +300,8 @@ typedef struct rtamd_scene_desc {
                                            hi.xyz and two unused (conservative, rounded
                                            outward); zeros for other nodes.  A ray that crosses
                                            the leaf's cell but misses this box skips the leaf */
+    const rtamd_transform *transforms;  /* device, NULL when n_transforms == 0: inner levels of nested
+                                           Instances */
 } rtamd_scene_desc;
 
 /* Camera and view plane (camera.py:12-33, :142-146, :222-225; tracer.py:91-95). */

@@ -62,6 +62,7 @@ PLAN = {
     "features_texture": ("parallel", None, 5000),
     "glass_teapot":     ("parallel", None, 2500),
     "features_pile":    ("parallel", None, 300),
+    "features_nested":  ("parallel", None, 5000),
     # RegularSampler everywhere (the scene files' "realtime" branch): no draws at all
     "glossyreflective@realtime": ("realtime", None, 3000),
     "mirrorhall@realtime": ("realtime", None, 2000),

@@ -233,8 +233,7 @@ typedef struct {
     int material, object, prim;
 } hit_t;
 
-static ray_t inv_ray(const rtamd_object *ob, const ray_t *r) {       /* geometry.py:97-101 */
-    const double *m = ob->inv_point, *n = ob->inv_dir;
+static ray_t inv_ray_one(const double *m, const double *n, const ray_t *r) {       /* geometry.py:97-101 */
     ray_t q;
     q.o = V(((m[0] * r->o.x + m[1] * r->o.y) + m[2] * r->o.z) + m[3],
             ((m[4] * r->o.x + m[5] * r->o.y) + m[6] * r->o.z) + m[7],
@@ -243,6 +242,23 @@ static ray_t inv_ray(const rtamd_object *ob, const ray_t *r) {       /* geometry
             (n[3] * r->d.x + n[4] * r->d.y) + n[5] * r->d.z,
             (n[6] * r->d.x + n[7] * r->d.y) + n[8] * r->d.z);
     return q;
+}
+
+/* Instance.inv_ray through every level of a nested Instance, outermost first (each level's hit()
+ * calls the wrapped object's, geometry.py:103-105) */
+static ray_t inv_ray(const rtamd_scene_desc *S, const rtamd_object *ob, const ray_t *r) {
+    ray_t q = inv_ray_one(ob->inv_point, ob->inv_dir, r);
+    int j;
+    for (j = 0; j < ob->n_inner; ++j) {
+        const rtamd_transform *t = &S->transforms[ob->inner_offset + j];
+        q = inv_ray_one(t->inv_point, t->inv_dir, &q);
+    }
+    return q;
+}
+
+static vec normal_out(const double *m, vec n) {                                    /* geometry.py:107 */
+    return V((m[0] * n.x + m[3] * n.y) + m[6] * n.z, (m[1] * n.x + m[4] * n.y) + m[7] * n.z,
+             (m[2] * n.x + m[5] * n.y) + m[8] * n.z);
 }
 
 static int sphere_root(const double *p, const ray_t *r, vec *temp, double *t) {   /* geometry.py:254-269 */
@@ -325,7 +341,7 @@ static void bare_triangle(const double *p, double g[9]) {
 static int object_hit(ctx_t *c, int idx, const ray_t *world_ray, hit_t *h) {
     const rtamd_scene_desc *S = c->S;
     const rtamd_object *ob = &S->objects[idx];
-    ray_t local = ob->has_transform ? inv_ray(ob, world_ray) : *world_ray;
+    ray_t local = ob->has_transform ? inv_ray(S, ob, world_ray) : *world_ray;
     const ray_t *r = &local;
     const double *p = ob->p;
     double t = 0;
@@ -401,10 +417,10 @@ static int object_hit(ctx_t *c, int idx, const ray_t *world_ray, hit_t *h) {
     default: break;
     }
     if (!hit) return 0;
-    if (ob->has_transform) {                                              /* geometry.py:107 */
-        const double *m = ob->inv_dir;
-        n = V((m[0] * n.x + m[3] * n.y) + m[6] * n.z, (m[1] * n.x + m[4] * n.y) + m[7] * n.z,
-              (m[2] * n.x + m[5] * n.y) + m[8] * n.z);
+    if (ob->has_transform) {                                              /* geometry.py:107, innermost level first */
+        int j;
+        for (j = ob->n_inner - 1; j >= 0; --j) n = normal_out(S->transforms[ob->inner_offset + j].inv_dir, n);
+        n = normal_out(ob->inv_dir, n);
     }
     h->t = t; h->n = n; h->material = mat; h->object = idx; h->prim = prim;
     h->local = add(r->o, scl(r->d, t));                                   /* geometry.py:210, :323, :456 ... */
@@ -416,7 +432,7 @@ static int object_hit(ctx_t *c, int idx, const ray_t *world_ray, hit_t *h) {
 static int object_shadow(ctx_t *c, int idx, const ray_t *world_ray, double *t) {
     const rtamd_scene_desc *S = c->S;
     const rtamd_object *ob = &S->objects[idx];
-    ray_t local = ob->has_transform ? inv_ray(ob, world_ray) : *world_ray;
+    ray_t local = ob->has_transform ? inv_ray(S, ob, world_ray) : *world_ray;
     const ray_t *r = &local;
     const double *p = ob->p;
     if (ob->kind == RTAMD_KDTREE) {                                       /* kdtree.py:157-164 */

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(HERE, "csrc", "librtamd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_BRANCH_LEVELS = 8
 N_COUNTERS = 16
 COUNT_WORK = 1
@@ -23,9 +23,13 @@ d3 = C.c_double * 3
 class Object(C.Structure):
     _fields_ = [("kind", C.c_int32), ("material", C.c_int32), ("alt_material", C.c_int32),
                 ("cast_shadow", C.c_int32), ("has_transform", C.c_int32), ("tree", C.c_int32),
-                ("smooth", C.c_int32), ("reserved", C.c_int32),
+                ("smooth", C.c_int32), ("n_inner", C.c_int32),
                 ("p", C.c_double * 30), ("inv_point", C.c_double * 12),
-                ("inv_dir", C.c_double * 9), ("pad_", C.c_double)]
+                ("inv_dir", C.c_double * 9), ("inner_offset", C.c_int32), ("pad_", C.c_int32)]
+
+
+class Transform(C.Structure):
+    _fields_ = [("inv_point", C.c_double * 12), ("inv_dir", C.c_double * 9), ("pad_", C.c_double * 3)]
 
 
 class Material(C.Structure):
@@ -82,9 +86,9 @@ class SceneDesc(C.Structure):
                 ("tri_order", C.c_void_p), ("tri_rows", C.c_void_p), ("leaf_boxes", C.c_void_p), ("chunk_boxes", C.c_void_p),
                 ("prim_normals", C.c_void_p), ("prim_normal_offset", C.c_void_p),
                 ("prim_material", C.c_void_p),
-                ("n_textures", C.c_int32), ("reserved", C.c_int32), ("n_texel_bytes", C.c_int64),
+                ("n_textures", C.c_int32), ("n_transforms", C.c_int32), ("n_texel_bytes", C.c_int64),
                 ("textures", C.c_void_p), ("texels", C.c_void_p), ("chunk_tree", C.c_void_p),
-                ("leaf_aabb", C.c_void_p)]
+                ("leaf_aabb", C.c_void_p), ("transforms", C.c_void_p)]
 
 
 class Camera(C.Structure):

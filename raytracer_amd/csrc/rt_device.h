@@ -1160,9 +1160,7 @@ __device__ __forceinline__ bool box_shadow(const double* p, const Ray& r, double
 }
 
 // Instance.inv_ray (geometry.py:97-101): the direction is not renormalised.
-__device__ __forceinline__ Ray to_object_space(const rtamd_object& ob, const Ray& r) {
-    const double* m = ob.inv_point;
-    const double* n = ob.inv_dir;
+__device__ __forceinline__ Ray inverse_ray(const double* m, const double* n, const Ray& r) {
     Ray q;
     q.o = v3(((m[0] * r.o.x + m[1] * r.o.y) + m[2] * r.o.z) + m[3],
              ((m[4] * r.o.x + m[5] * r.o.y) + m[6] * r.o.z) + m[7],
@@ -1173,11 +1171,25 @@ __device__ __forceinline__ Ray to_object_space(const rtamd_object& ob, const Ray
     return q;
 }
 // Instance.hit (geometry.py:107): normal through the transposed inverse, not renormalised.
-__device__ __forceinline__ V3 normal_to_world(const rtamd_object& ob, V3 nrm) {
-    const double* n = ob.inv_dir;
+__device__ __forceinline__ V3 transposed_normal(const double* n, V3 nrm) {
     return v3((n[0] * nrm.x + n[3] * nrm.y) + n[6] * nrm.z,
               (n[1] * nrm.x + n[4] * nrm.y) + n[7] * nrm.z,
               (n[2] * nrm.x + n[5] * nrm.y) + n[8] * nrm.z);
+}
+// A ray into the space of the object an Instance wraps: through the outermost Instance first,
+// then through the nested ones from the outside in (each Instance.hit calls the next).
+__device__ __forceinline__ Ray to_object_space(const rtamd_scene_desc& S, const rtamd_object& ob, const Ray& r) {
+    Ray q = inverse_ray(ob.inv_point, ob.inv_dir, r);
+    for (int j = 0; j < ob.n_inner; ++j) {
+        const rtamd_transform& t = S.transforms[ob.inner_offset + j];
+        q = inverse_ray(t.inv_point, t.inv_dir, q);
+    }
+    return q;
+}
+// The hit's normal on its way back out: innermost Instance first.
+__device__ __forceinline__ V3 normal_to_world(const rtamd_scene_desc& S, const rtamd_object& ob, V3 nrm) {
+    for (int j = ob.n_inner - 1; j >= 0; --j) nrm = transposed_normal(S.transforms[ob.inner_offset + j].inv_dir, nrm);
+    return transposed_normal(ob.inv_dir, nrm);
 }
 
 // ---------------------------------------------------------------- world queries
@@ -1197,7 +1209,7 @@ __device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, 
     bool any = false;
     for (int i = 0; i < S.n_objects; ++i) {
         const rtamd_object& ob = S.objects[i];
-        const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+        const Ray r = ob.has_transform ? to_object_space(S, ob, ray) : ray;
         const double* p = ob.p;
         double t = 0;
         V3 n = v3(0, 0, 0);
@@ -1208,7 +1220,9 @@ __device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, 
                 const rtamd_tree& T = S.trees[ob.tree];
                 TriHit th;
                 bool f;
+                w.mark(44);     // closest hit: object and tree records, ray into object space
                 kd_query_wave<COUNT, false>(S, T, active, r, 0.0, coherent, stk, w, f, th);
+                w.mark(45);     // closest hit: the kd query, root box included
                 if (active && f) {
                     hit = true;
                     t = th.t;
@@ -1219,6 +1233,7 @@ __device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, 
                                  : ld3(nn);
                     mat = S.prim_material[gp];
                 }
+                w.mark(46);     // closest hit: normal and material of the row that was hit
             }
         } else if (active) {
             w.analytic();
@@ -1263,7 +1278,7 @@ __device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, 
             tmin = t;
             any = true;
             h.t = t;
-            h.n = ob.has_transform ? normal_to_world(ob, n) : n;
+            h.n = ob.has_transform ? normal_to_world(S, ob, n) : n;
             h.material = mat;
             h.object = i;
             h.prim = prim;
@@ -1309,7 +1324,7 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
             const rtamd_object& ob = S.objects[i];
             if (ob.kind == RTAMD_KDTREE) { tree_object = i; continue; }
             if (!(need && !occ && ob.cast_shadow)) continue;
-            const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+            const Ray r = ob.has_transform ? to_object_space(S, ob, ray) : ray;
             double t = 0;
             w.analytic();
             if (analytic_shadow(ob, r, t) && (!use_limit || t < limit)) occ = true;
@@ -1317,7 +1332,7 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
         const rtamd_object& ob = S.objects[tree_object];
         const bool q = need && !occ;
         if (__ballot(q)) {
-            const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+            const Ray r = ob.has_transform ? to_object_space(S, ob, ray) : ray;
             TriHit th;
             bool f;
             kd_query_wave<COUNT, true>(S, S.trees[ob.tree], q, r, use_limit ? limit : T_INF * 4.0, false, stk, w, f, th);
@@ -1332,7 +1347,7 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
         for (int i = 0; i < S.n_objects; ++i) {
             const rtamd_object& ob = S.objects[i];
             if (ob.kind == RTAMD_KDTREE || !(need && !occ && ob.cast_shadow)) continue;
-            const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+            const Ray r = ob.has_transform ? to_object_space(S, ob, ray) : ray;
             double t = 0;
             w.analytic();
             if (analytic_shadow(ob, r, t) && (!use_limit || t < limit)) occ = true;
@@ -1342,7 +1357,7 @@ __device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, boo
         const rtamd_object& ob = S.objects[i];
         if (TREES && COUNT != 1 && ob.kind != RTAMD_KDTREE) continue;
         const bool q = need && !occ;
-        const Ray r = ob.has_transform ? to_object_space(ob, ray) : ray;
+        const Ray r = ob.has_transform ? to_object_space(S, ob, ray) : ray;
         double t = 0;
         bool hit = false;
         if (TREES && ob.kind == RTAMD_KDTREE) {
@@ -1395,8 +1410,8 @@ __device__ __forceinline__ V3 phong_lobe(V3 spec, double exp_, V3 n, V3 wo, V3 w
 // ShadeRecord.local_hit_point of a hit: o + t*d in the object's own space (geometry.py:210,
 // :323, :456; through an Instance the child's record is kept, :103-108), relative to the
 // centre for a sphere (:271).
-__device__ __forceinline__ V3 local_hit_point(const rtamd_object& ob, const Ray& world_ray, double t) {
-    const Ray r = ob.has_transform ? to_object_space(ob, world_ray) : world_ray;
+__device__ __forceinline__ V3 local_hit_point(const rtamd_scene_desc& S, const rtamd_object& ob, const Ray& world_ray, double t) {
+    const Ray r = ob.has_transform ? to_object_space(S, ob, world_ray) : world_ray;
     V3 p = r.o + t * r.d;
     if (ob.kind == RTAMD_SPHERE) p = p - ld3(ob.p);
     return p;
@@ -1634,7 +1649,7 @@ __device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool ali
 
         V3 tex = v3(1, 1, 1);
         if (EXT && alive && m.kind == RTAMD_SV_MATTE)
-            tex = texture_color(S, m.texture, local_hit_point(S.objects[h.object], ray, h.t));
+            tex = texture_color(S, m.texture, local_hit_point(S, S.objects[h.object], ray, h.t));
         const V3 Ld = direct_light_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, alive, m, h, wo, area, tex, dr, w);
         if (alive) L = L + W * Ld;
         // the AreaLightTracer never bounces: leaving here makes the body straight-line code, so

@@ -504,6 +504,10 @@ static int scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
             return fail(RTAMD_EINVAL, "a material that samples a lobe has no sampler%s");
         }
     }
+    if (d->n_transforms < 0 || (d->n_transforms && !d->transforms)) {
+        rtamd_scene_destroy(s);
+        return fail(RTAMD_EINVAL, "transform table missing%s");
+    }
     if (d->n_textures < 0 || (d->n_textures && (!d->textures || !d->texels))) {
         rtamd_scene_destroy(s);
         return fail(RTAMD_EINVAL, "texture tables missing%s");
@@ -544,6 +548,11 @@ static int scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
         const rtamd_object& o = objects[i];
         const bool tree = o.kind == RTAMD_KDTREE;
         if (tree) s->tree_objects++;
+        if (o.n_inner < 0 || (o.n_inner > 0 && (!o.has_transform || o.inner_offset < 0 ||
+                                                 (int64_t)o.inner_offset + o.n_inner > d->n_transforms))) {
+            rtamd_scene_destroy(s);
+            return fail(RTAMD_EINVAL, "an object's nested transforms lie outside the transform table%s");
+        }
         if (o.kind < RTAMD_SPHERE || o.kind > RTAMD_KDTREE || (tree && (o.tree < 0 || o.tree >= d->n_trees)) ||
             (!tree && (o.material < 0 || o.material >= d->n_materials)) ||
             (o.kind == RTAMD_CHECKER_PLANE && (o.alt_material < 0 || o.alt_material >= d->n_materials))) {

@@ -31,7 +31,7 @@ class FlatScene(object):
 
     TABLES = ("objects", "materials", "lights", "samplers", "sampler_data", "trees",
               "kd_nodes", "tri_geom", "tri_prim", "prim_normals", "prim_normal_offset",
-              "prim_material", "textures", "texels")
+              "prim_material", "textures", "texels", "transforms")
 
     def __init__(self):
         self.arrays = {}
@@ -63,6 +63,7 @@ class FlatScene(object):
         d.n_sampler_doubles = len(a["sampler_data"])
         d.n_textures = len(a["textures"]) // C.sizeof(capi.Texture)
         d.n_texel_bytes = len(a["texels"])
+        d.n_transforms = len(a["transforms"]) // C.sizeof(capi.Transform)
         d.background[:] = list(self.background)
         d.ambient = self.ambient
         for name in self.TABLES:
@@ -87,6 +88,7 @@ class _Flattener(object):
         self.materials, self.material_ids = [], {}
         self.textures, self.texture_ids, self.texels, self.n_texel_bytes = [], {}, [], 0
         self.trees = []
+        self.transforms = []
         self.kd_nodes = []
         self.tri_geom, self.tri_prim = [], []
         self.prim_normals, self.prim_normal_offset, self.prim_material = [], [], []
@@ -225,11 +227,19 @@ class _Flattener(object):
         target = obj
         if isinstance(obj, G.Instance):
             target = obj.obj
-            if isinstance(target, G.Instance):
-                raise NotImplementedError("nested Instance objects")
             o.has_transform = 1
             _fill(o.inv_point, numpy.asarray(obj.inv_transform)[:3, :4])
             _fill(o.inv_dir, numpy.asarray(obj.inv_normal_transform)[:3, :3])
+            # an Instance of an Instance (geometry.py:85-112 wraps any object): the further
+            # levels, from the outside in
+            o.inner_offset = len(self.transforms)
+            while isinstance(target, G.Instance):
+                t = capi.Transform()
+                _fill(t.inv_point, numpy.asarray(target.inv_transform)[:3, :4])
+                _fill(t.inv_dir, numpy.asarray(target.inv_normal_transform)[:3, :3])
+                self.transforms.append(t)
+                o.n_inner += 1
+                target = target.obj
         if isinstance(target, K.KDTree):
             o.kind = capi.KDTREE
             o.tree = self.add_tree(target)
@@ -385,6 +395,7 @@ def flatten_world(world):
     a["prim_material"] = _cat(fl.prim_material, numpy.int32)
     a["textures"] = pack(fl.textures, capi.Texture)
     a["texels"] = _cat(fl.texels, numpy.uint8)
+    a["transforms"] = pack(fl.transforms, capi.Transform)
     scene.sampler_objects = fl.samplers
     scene.n_trees = len(fl.trees)
     return scene

@@ -176,3 +176,50 @@ class Pile(BuildFunctionBase):
             Plane(origin=(0, 0, 0), normal=(0, 1, 0), material=Matte(ka=.6, kd=.8, cd=_rgb(.8, .8, .8))),
         ]
         world.lights = [PointLight(_rgb(1, 1, 1), 2.0, numpy.array((4., 7., 5.)), radius=8, attenuation=2, cast_shadow=True)]
+
+
+class NestedInstances(BuildFunctionBase):
+    """Instances of Instances (geometry.py:85-112 wraps any object): a sphere seen through two
+    transforms, a box through three, and the small flat mesh's kd-tree through two, over a
+    checker plane with a mirror ball; point light with shadows, one mirror bounce."""
+    BUILD_FUNCTION_NAME = 'features_nested'
+
+    @classmethod
+    def build_function(cls, world, viewmode):
+        world.viewmode = viewmode
+        dim = 1 if viewmode == "realtime" else 2
+        sampler = MultiJitteredSampler(sample_dim=dim)
+        world.viewplane = ViewPlane(resolution=(160, 120), pixel_size=2.0, sampler=sampler)
+        world.camera = PinholeCamera(eye=(7., 5., 10.), up=(0., 1., 0.), lookat=(0., 1., 0.), viewing_distance=240.)
+        world.background_color = (0.04, 0.05, 0.08)
+        world.tracer = Tracer(world, 3)
+        world.ambient_color = AmbientLight(_rgb(1, 1, 1), .3)
+
+        chalk = Matte(ka=.7, kd=.9, cd=_rgb(.9, .9, .85))
+        moss = Matte(ka=.7, kd=.9, cd=_rgb(.35, .7, .4))
+        brass = Phong(ka=.5, kd=.7, ks=.6, exp=40, cd=_rgb(.9, .7, .2))
+        clay = Matte(ka=.6, kd=.8, cd=_rgb(.85, .5, .35))
+        mirror = Reflective(ka=.2, kd=.3, ks=.5, kr=.8, exp=120, cd=_rgb(.9, .95, 1.))
+
+        stretch = transform.scale(1.5, 0.7, 1.0)
+        turn = transform.rotate(numpy.array((0.2, 1., 0.4)), 0.9)
+        lift = transform.translate(-3.0, 1.4, 0.5)
+        lean = transform.rotate(numpy.array((1., 0., 0.3)), 0.4)
+        away = transform.translate(3.2, 1.0, -2.0)
+        with open('meshes/mesh1.obj') as f:
+            mesh = read_mesh(f)
+        mesh.material = clay
+        tree = KDTree(BoundingBoxes(mesh.get_bounding_boxes()))
+        grow = transform.scale(9., 9., 9.)
+        spin = transform.translate(0.5, 2.6, -3.5).dot(transform.rotate(numpy.array((0., 1., 0.)), 2.2))
+        world.objects = [
+            CheckerPlane(origin=(0, 0, 0), normal=(0, 1, 0), material=chalk, alt_material=moss,
+                         up=(1, 0, 0), grid_size=1.5),
+            Instance(Instance(Sphere(center=_rgb(0, 0, 0), radius=1., material=brass), stretch), lift.dot(turn)),
+            Instance(Instance(Instance(AxisAlignedBox(-0.6, 0.6, -0.6, 0.6, -0.6, 0.6, material=moss), stretch), lean), away),
+            Instance(Instance(tree, grow), spin),
+            Sphere(center=_rgb(0.5, 1.0, 2.5), radius=1.0, material=mirror),
+        ]
+        world.lights = [
+            PointLight(_rgb(1, 1, 1), 1.6, numpy.array((-1., 7., 5.)), radius=7, attenuation=2, cast_shadow=True),
+        ]

@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 GOLDEN_SCENES = ("foursphere", "glossyreflective", "mirrorhall", "mirrorhall_dof", "cornellbox",
                  "cornellbox_area", "features_analytic", "features_mesh", "features_env", "features_glass",
                  "features_pane", "features_pile", "features_texture", "glass_teapot", "j", "dragon_area",
-                 "k", "mirror", "mirroralt",
+                 "k", "mirror", "mirroralt", "features_nested",
                  "glossyreflective@realtime", "mirrorhall@realtime")
 
 # float comparison bound for radiance: the tolerance of the task statement is 1e-4

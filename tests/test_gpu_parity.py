@@ -39,6 +39,7 @@ def test_gpu_matches_reference_golden(torch_gpu, scene):
     ("features_glass", 60, (0, 9)),
     ("features_pane", 40, (1, 4)),
     ("features_pile", 48, (0, 4)),
+    ("features_nested", 80, (0, 4)),
     ("features_texture", 70, (0, 9)),
     ("glass_teapot", 80, (0, 4)),
     ("glossyreflective@realtime", 64, (0, 1)),

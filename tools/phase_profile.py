@@ -76,6 +76,8 @@ def main():
                               "light_shadow_incl_kd": t[19] / float(total), "ray_generation": t[32] / float(total),
                               "hit_to_ambient_ray": t[33] / float(total), "light_setup": t[34] / float(total),
                               "shade_and_write": t[35] / float(total)}
+    out["closest_hit_parts"] = {"before_kd_query": t[44] / float(total), "kd_query_with_root_box": t[45] / float(total),
+                                "hit_row_normal_and_material": t[46] / float(total)}
     if t[28]:
         out["shadow_rounds"] = {"rounds": t[28], "lanes_walking_per_round": t[29] / float(t[28])}
     print(json.dumps(out, indent=1))
