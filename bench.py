@@ -49,7 +49,7 @@ WORKLOADS = {
     "dragon_1080p_16spp_ao_arealight": ("dragon_area", dict(resolution=(1920, 1080), sample_dim=4)),
     "dragon_480x270_16spp_ao_arealight": ("dragon_area", dict(resolution=(480, 270), sample_dim=4)),
     "cornellbox_200_16spp_arealight": ("cornellbox_area", None),
-    # the other BASELINE configurations, for profiling tools (bench lines are quoted on the dragon frame)
+    # the other benchmark configurations, for profiling tools (bench lines are quoted on the dragon frame)
     "foursphere_200_1spp": ("foursphere", None),
     "glossyreflective_400_100spp": ("glossyreflective", None),
     "mirrorhall_4k_64spp_dof": ("mirrorhall_dof", dict(resolution=(3840, 2160), sample_dim=8)),

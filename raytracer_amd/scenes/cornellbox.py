@@ -2,7 +2,7 @@
 
 'cornellbox' is the world of /root/reference/buildfunctions/cornellbox.py:18-54: path
 traced, 100 samples per pixel.
-'cornellbox_area' is BASELINE config 2: 16 samples per pixel, the ceiling quad as an
+'cornellbox_area' is benchmark configuration 2: 16 samples per pixel, the ceiling quad as an
 area light with soft shadows (AreaLightTracer); the quad lies in an xz-plane, which
 `Rectangle.sample` cannot express (geometry.py:378-380), so the light's shape is the
 small class below with the same three methods an AreaLight calls."""

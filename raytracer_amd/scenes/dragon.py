@@ -2,7 +2,7 @@
 
 'j' is the world of /root/reference/buildfunctions/j.py:18-53: 400x400, one sample,
 matte dragon on a ground plane, one shadow-casting point light.
-'dragon_area' is BASELINE config 4: 1920x1080, 16 samples per pixel, ambient occlusion
+'dragon_area' is benchmark configuration 4: 1920x1080, 16 samples per pixel, ambient occlusion
 plus a rectangular area light (soft shadows), AreaLightTracer."""
 import numpy
 from buildfunctionbase import BuildFunctionBase

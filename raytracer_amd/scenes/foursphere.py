@@ -1,5 +1,5 @@
 """Four mirror spheres around a point light, 200x200, one sample per pixel, 20 bounces.
-Same world as /root/reference/buildfunctions/foursphere.py:18-60 (BASELINE config 1)."""
+Same world as /root/reference/buildfunctions/foursphere.py:18-60 (benchmark configuration 1)."""
 import numpy
 from buildfunctionbase import BuildFunctionBase
 from camera import PinholeCamera

@@ -1,5 +1,5 @@
 """Glossy and matte spheres on a checker floor, 400x400, 100 samples per pixel.
-Same world as /root/reference/buildfunctions/glossyreflective.py:18-69 (BASELINE config 3)."""
+Same world as /root/reference/buildfunctions/glossyreflective.py:18-69 (benchmark configuration 3)."""
 import numpy
 from buildfunctionbase import BuildFunctionBase
 from camera import PinholeCamera

@@ -2,7 +2,7 @@
 
 'mirrorhall' is the world of /root/reference/buildfunctions/mirrorhall.py:18-54
 (200x200, one sample, pinhole).  'mirrorhall_dof' is the 4K depth-of-field variant of
-BASELINE config 5: 3840x2160, 64 samples per pixel, thin-lens camera, and the sphere
+benchmark configuration 5: 3840x2160, 64 samples per pixel, thin-lens camera, and the sphere
 placed through an affine Instance (stretched and tilted) next to a second plain one."""
 import numpy
 import affinetransform as transform

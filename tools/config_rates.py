@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput and vector-lane use of the five BASELINE.json configurations (and two of the
+"""Throughput and vector-lane use of the five benchmark configurations (and two of the
 reference's scenes as shipped) on one GPU.
 
   python tools/config_rates.py [--no-pmc] [--lib PATH] [--out FILE] [label substring ...]
