@@ -501,3 +501,86 @@ def test_two_tree_objects_under_the_area_tracer(torch_gpu):
     want, _, per = osc.render_tiles(cam, world.seed, tiles, 0, 4, per_sample_want=("rgb",), threads=8)
     assert work == osc.read_counters(reset=True)
     common.assert_integer_sums_match(counted.sum_rgb8.cpu().numpy(), want, per["rgb"], len(tiles), 4, "two trees")
+
+
+@pytest.mark.parametrize("scene,overrides,oracle_tiles", [
+    ("glossyreflective", None, 24),                                                   # 400x400, 100 samples per pixel
+    ("mirrorhall_dof", dict(resolution=(3840, 2160), sample_dim=8), 6),               # 4K, 64 samples per pixel
+])
+def test_full_size_analytic_frames(torch_gpu, scene, overrides, oracle_tiles):
+    """The two full-size configurations without a kd-tree: the timed kernel, the kernel that counts
+    the reference's work and the one that counts executed work render the same integer frame;
+    split over sample ranges it is the same frame again; random tiles equal the oracle's."""
+    from raytracer_amd import flatten, runtime
+    from raytracer_amd.world import World
+    from oracle import oracle
+    torch = torch_gpu
+    world = World.__new__(World)
+    if overrides:
+        world.overrides = overrides
+    World.__init__(world, viewmode="parallel", buildfunction=scene, seed=1)
+    ds = runtime.device_scene(world)
+    cam = flatten.camera_record(world)
+    tx, ty = runtime.tile_grid(cam.width, cam.height)
+    tiles = numpy.arange(tx * ty, dtype=numpy.int32)
+    ns = len(world.viewplane.sampler.patterns[0])
+
+    def render(s0, s1, into=None, **kw):
+        fb = into if into is not None else runtime.FrameBuffers(ds, tiles)
+        ds.render_tiles(cam, world.seed, fb.tile_ids, s0, s1, sum_rgb8=fb.sum_rgb8, **kw)
+        torch.cuda.synchronize()
+        return fb
+
+    ds.read_counters(reset=True)
+    whole = render(0, ns)
+    c = ds.read_counters(reset=True)
+    assert c["samples"] == cam.width * cam.height * ns and c["closest"] >= c["samples"]
+    counted = render(0, ns, count_work=True)
+    work = ds.read_counters(reset=True)
+    assert torch.equal(counted.sum_rgb8, whole.sum_rgb8)
+    executed = render(0, ns, count_executed=True)
+    done = ds.read_counters(reset=True, executed=True)
+    assert torch.equal(executed.sum_rgb8, whole.sum_rgb8)
+    assert (done["closest"], done["shadow"]) == (c["closest"], c["shadow"]) == (work["closest"], work["shadow"])
+    assert done["analytic_tests"] == work["analytic_tests"] > 0 and done["bytes_loaded"] == 48 * done["analytic_tests"]
+    parts = render(0, ns // 2)
+    render(ns // 2, ns, into=parts)
+    assert torch.equal(parts.sum_rgb8, whole.sum_rgb8)
+    del counted, executed, parts
+    pick = numpy.sort(numpy.random.RandomState(8).choice(tx * ty, size=oracle_tiles, replace=False)).astype(numpy.int32)
+    want, _, per = oracle.OracleScene(ds.flat).render_tiles(cam, world.seed, pick, 0, ns, per_sample_want=("rgb",), threads=8)
+    got = whole.sum_rgb8.cpu().numpy().reshape(-1, 64, 3)[pick].reshape(-1, 3)
+    common.assert_integer_sums_match(got, want, per["rgb"], len(pick), ns, scene)
+
+
+def test_executed_work_counters_on_the_dragon(torch_gpu):
+    """RTAMD_COUNT_EXECUTED runs the fast path and tallies it: same frame as the timed kernel, far
+    fewer triangle tests than the reference's scan, and loads that add up."""
+    from raytracer_amd import flatten, runtime
+    torch = torch_gpu
+    world = common.world_for("dragon_area")
+    ds = runtime.device_scene(world)
+    cam = flatten.camera_record(world)
+    tx, ty = runtime.tile_grid(cam.width, cam.height)
+    tiles = numpy.arange(tx * ty, dtype=numpy.int32)
+    frames = {}
+    for mode in ("timed", "executed", "reference"):
+        fb = runtime.FrameBuffers(ds, tiles)
+        ds.read_counters(reset=True)
+        ds.render_tiles(cam, world.seed, fb.tile_ids, 0, 16, sum_rgb8=fb.sum_rgb8,
+                        count_executed=mode == "executed", count_work=mode == "reference")
+        torch.cuda.synchronize()
+        frames[mode] = (fb.sum_rgb8, ds.read_counters(reset=True, executed=True))
+    assert torch.equal(frames["timed"][0], frames["executed"][0]) and torch.equal(frames["timed"][0], frames["reference"][0])
+    done, ref = frames["executed"][1], frames["reference"][1]
+    assert (done["closest"], done["shadow"]) == (ref["closest"], ref["shadow"])
+    assert 0 < done["tri_tests"] < ref["tri_tests"] / 4                 # boxes cull most of the reference's tests
+    assert done["rows_loaded"] <= done["tri_tests"]                      # a loaded row may serve several rays
+    assert done["leaves_skipped"] <= done["kd_leaves"] and done["node_records"] > 0 and done["boxes_tested"] > 0
+    floor = 48 * done["node_records"] + 32 * done["boxes_tested"] + 72 * done["rows_loaded"] + 48 * done["analytic_tests"]
+    assert floor <= done["bytes_loaded"] <= floor + 16 * done["boxes_tested"] + 8 * done["rows_loaded"]
+    # both flags at once are refused
+    from raytracer_amd import capi
+    with pytest.raises(RuntimeError):
+        fb = runtime.FrameBuffers(ds, tiles)
+        ds.render_tiles(cam, world.seed, fb.tile_ids, 0, 16, sum_rgb8=fb.sum_rgb8, count_executed=True, count_work=True)
