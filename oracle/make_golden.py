@@ -63,6 +63,10 @@ PLAN = {
     "glass_teapot":     ("parallel", None, 2500),
     "features_pile":    ("parallel", None, 300),
     "features_nested":  ("parallel", None, 5000),
+    # seeded random worlds (raytracer_amd/scenes/fuzz.py)
+    "fuzz_0": ("parallel", None, 3000), "fuzz_1": ("parallel", None, 3000), "fuzz_2": ("parallel", None, 3000),
+    "fuzz_3": ("parallel", None, 3000), "fuzz_4": ("parallel", None, 3000), "fuzz_5": ("parallel", None, 3000),
+    "fuzz_6": ("parallel", None, 3000), "fuzz_7": ("parallel", None, 3000), "fuzz_8": ("parallel", None, 3000),
     # RegularSampler everywhere (the scene files' "realtime" branch): no draws at all
     "glossyreflective@realtime": ("realtime", None, 3000),
     "mirrorhall@realtime": ("realtime", None, 2000),

@@ -626,6 +626,33 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         int32_t first = 0, count = 0, cbase = -1;
         bool parked = false;
         int skips = 0, loads = 0;
+        unsigned long long my_chunks = 0;
+        bool my_any_hit_decides = true;
+        bool boxes_done = false;
+        // Shadow queries on boxed leaves: the lane tests its ray against the chunk boxes of its
+        // leaf, leaving a mask of touched chunks.  48-byte rows of floats: the chunk's box, then
+        // the box around a group of four chunks (in the row of the group's first chunk); a group
+        // the ray misses is skipped whole.
+        auto chunk_boxes_of_leaf = [&]() {
+            const int32_t nch = (count + 63) >> 6;
+            double tn, tf;
+            const float* rec = S.chunk_tree + (int64_t)cbase * 12;
+            my_chunks = 0;
+            my_any_hit_decides = true;
+            for (int32_t g = 0; g < nch; g += 4) {
+                if (nch > 4) w.x_box(32);
+                if (nch > 4 && !box_touch_f_second(rec + g * 12, r, inv_d, tn, tf)) continue;
+                const int32_t g_end = min(g + 4, nch);
+                for (int32_t j = g; j < g_end; ++j) {
+                    w.x_box(32);
+                    if (box_touch_f(rec + j * 12, r, inv_d, tn, tf)) {
+                        my_chunks |= 1ull << j;
+                        if (!(tf < limit)) my_any_hit_decides = false;
+                    }
+                }
+            }
+            boxes_done = true;
+        };
         if (walking) {
             // One interior step of KDTree.iterate_nodes (kdtree.py:140-153) at `node`, whose
             // record is nd: picks the next node and pushes the far child where the ray
@@ -780,31 +807,9 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
         // the chunk boxes of its own leaf (lanes of a wave mostly share a few big leaves, so
         // these loads coalesce), leaving a mask of touched chunks.  The rays are then taken
         // one at a time below, with no box step of their own.
-        unsigned long long my_chunks = 0;
-        bool my_any_hit_decides = true;
 #ifndef RT_NO_BOX_PREPASS
         const bool prepass = SHADOW && S.chunk_tree != nullptr;
-        if (prepass && at_leaf && !small && cbase >= 0 && count <= 4096) {
-            const V3 inv = inv_d;
-            const int32_t nch = (count + 63) >> 6;
-            double tn;
-            // 48-byte rows of floats: the chunk's box, then the box around a group of four chunks
-            // (in the row of the group's first chunk); a group the ray misses is skipped whole
-            const float* rec = S.chunk_tree + (int64_t)cbase * 12;
-            double tf;
-            for (int32_t g = 0; g < nch; g += 4) {
-                if (nch > 4) w.x_box(32);
-                if (nch > 4 && !box_touch_f_second(rec + g * 12, r, inv, tn, tf)) continue;
-                const int32_t g_end = min(g + 4, nch);
-                for (int32_t j = g; j < g_end; ++j) {
-                    w.x_box(32);
-                    if (box_touch_f(rec + j * 12, r, inv, tn, tf)) {
-                        my_chunks |= 1ull << j;
-                        if (!(tf < limit)) my_any_hit_decides = false;
-                    }
-                }
-            }
-        }
+        if (prepass && at_leaf && !small && cbase >= 0 && count <= 4096 && !boxes_done) chunk_boxes_of_leaf();
 #else
         const bool prepass = false;
 #endif

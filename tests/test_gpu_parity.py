@@ -46,14 +46,27 @@ def test_gpu_matches_reference_golden(torch_gpu, scene):
     ("dragon_area", 40, (0, 4)),
     ("dragon_area", 420, (0, 16)),
     ("j", 600, (0, 1)),
-])
+] + [("fuzz_%d" % k, 96, None) for k in range(9)])                  # whole frames, every sample
 def test_gpu_tiles_match_oracle(torch_gpu, scene, tiles, samples):
     """Whole tiles through rtamd_render_tiles (ray generation on the device) against the
     CPU oracle: per-sample ids and counts exact, integer accumulators identical."""
+    check_tiles_against_oracle(torch_gpu, common.world_for(scene), common.flat_for(scene), tiles, samples, scene)
+
+
+@pytest.mark.parametrize("first", range(9, 45, 6))
+def test_random_worlds_match_oracle(torch_gpu, first):
+    """Six more seeded random worlds per case (raytracer_amd/scenes/fuzz.py), whole frames, every
+    sample, against the oracle (which the reference pins on the first nine of the family)."""
+    from raytracer_amd import flatten
+    from raytracer_amd.world import World
+    for k in range(first, first + 6):
+        world = World(viewmode="parallel", buildfunction="fuzz_%d" % k, seed=1)
+        check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), 96, None, "fuzz_%d" % k)
+
+
+def check_tiles_against_oracle(torch, world, flat, tiles, samples, scene):
     from raytracer_amd import flatten, runtime
     from oracle import oracle
-    torch = torch_gpu
-    world = common.world_for(scene)
     ds = runtime.device_scene(world)
     cam = flatten.camera_record(world)
     tx, ty = runtime.tile_grid(cam.width, cam.height)
@@ -61,7 +74,7 @@ def test_gpu_tiles_match_oracle(torch_gpu, scene, tiles, samples):
     tile_ids = numpy.sort(rng.choice(tx * ty, size=min(tiles, tx * ty), replace=False)).astype(numpy.int32)
     # always include the last tile (partial when the frame is not a multiple of 8)
     tile_ids[-1] = tx * ty - 1
-    s0, s1 = samples
+    s0, s1 = samples or (0, len(world.viewplane.sampler.patterns[0]))
     n = len(tile_ids) * 64 * (s1 - s0)
     fb = runtime.FrameBuffers(ds, tile_ids)
     per = ds.sample_buffers(n)
@@ -71,36 +84,31 @@ def test_gpu_tiles_match_oracle(torch_gpu, scene, tiles, samples):
     torch.cuda.synchronize()
     gpu_work = ds.read_counters(reset=True)
     got = {k: v.cpu().numpy() for k, v in per[0].items()}
-    osc = oracle.OracleScene(common.flat_for(scene))
+    osc = oracle.OracleScene(flat)
     want_rgb8, want_sq, want = osc.render_tiles(cam, world.seed, tile_ids, s0, s1,
                                                 per_sample_want=("rgb", "hit_object", "hit_prim", "hit_t", "n_rays"),
                                                 threads=8)
-    assert numpy.array_equal(got["hit_object"], want["hit_object"])
-    assert numpy.array_equal(got["hit_prim"], want["hit_prim"])
-    assert numpy.array_equal(got["n_rays"], want["n_rays"])
+    assert numpy.array_equal(got["hit_object"], want["hit_object"]), scene
+    assert numpy.array_equal(got["hit_prim"], want["hit_prim"]), scene
+    assert numpy.array_equal(got["n_rays"], want["n_rays"]), scene
     # the counting launch reports the work of the reference algorithm (kd steps, leaves,
     # triangle and analytic tests), whatever shortcuts the kernel takes: identical to the oracle's
-    assert gpu_work == osc.read_counters(reset=True)
+    assert gpu_work == osc.read_counters(reset=True), scene
     close, worst = common.rgb_close(got["rgb"], want["rgb"])
-    assert close, "worst relative error %g" % worst
+    assert close, "%s: worst relative error %g" % (scene, worst)
     # int(c*255) of one sample may differ by one only where c*255 is within rounding of an
     # integer (ambient-only pixels: 0.2*255 = 51.0 +- 1 ulp); a pixel's integer sum may
     # therefore differ by at most its number of such samples, and is identical otherwise
-    scaled = want["rgb"] * 255
-    with numpy.errstate(invalid="ignore"):
-        edge = numpy.abs(scaled - numpy.rint(scaled)) < 1e-6 * numpy.maximum(1.0, numpy.abs(scaled))
-    ns = s1 - s0
-    edge_per_pixel = edge.reshape(len(tile_ids), ns, 64, 3).sum(axis=1).reshape(-1, 3)
-    d = numpy.abs(fb.sum_rgb8.cpu().numpy() - want_rgb8)
-    assert (d <= edge_per_pixel).all(), "integer accumulators differ beyond rounding knife-edges"
-    assert numpy.allclose(fb.sum_sq.cpu().numpy(), want_sq, rtol=1e-8, atol=1e-12)
-    # the timed (non-counting) kernel variant gives the same frame
-    fb2 = runtime.FrameBuffers(ds, tile_ids)
-    ds.render_tiles(cam, world.seed, fb2.tile_ids, s0, s1, sum_rgb8=fb2.sum_rgb8)
-    torch.cuda.synchronize()
-    assert torch.equal(fb2.sum_rgb8, fb.sum_rgb8)
+    mismatches = common.assert_integer_sums_match(fb.sum_rgb8.cpu().numpy(), want_rgb8, want["rgb"], len(tile_ids), s1 - s0, scene)
+    assert numpy.allclose(fb.sum_sq.cpu().numpy(), want_sq, rtol=1e-8, atol=1e-12, equal_nan=True), scene
+    # the timed (non-counting) kernel and the one that counts executed work give the same frame
+    for flags in (dict(), dict(count_executed=True)):
+        fb2 = runtime.FrameBuffers(ds, tile_ids)
+        ds.render_tiles(cam, world.seed, fb2.tile_ids, s0, s1, sum_rgb8=fb2.sum_rgb8, **flags)
+        torch.cuda.synchronize()
+        assert torch.equal(fb2.sum_rgb8, fb.sum_rgb8), scene
     print("%s: %d samples, worst relative radiance error vs oracle %.3g, accumulator mismatches %d"
-          % (scene, n, worst, int((d > 0).sum())))
+          % (scene, n, worst, mismatches))
 
 
 def test_trace_rays_entry_point(torch_gpu):
