@@ -72,12 +72,13 @@ def main():
                                        "ray_chunk_pairs": t[22], "distinct_leaf_chunk_pairs": t[23]}
     if t[27]:
         out["packed_shadow_sharing"] = {"episodes": t[27], "rays": t[25], "distinct_leaves": t[26]}
-    out["marks_inclusive"] = {"closest_hit_incl_kd": t[31] / float(total), "ambient_occlusion_incl_kd": t[18] / float(total),
+    out["marks_inclusive"] = {"closest_hit_incl_kd": (t[31] + t[44] + t[45] + t[46]) / float(total), "ambient_occlusion_incl_kd": t[18] / float(total),
                               "light_shadow_incl_kd": t[19] / float(total), "ray_generation": t[32] / float(total),
                               "hit_to_ambient_ray": t[33] / float(total), "light_setup": t[34] / float(total),
                               "shade_and_write": t[35] / float(total)}
     out["closest_hit_parts"] = {"before_kd_query": t[44] / float(total), "kd_query_with_root_box": t[45] / float(total),
-                                "hit_row_normal_and_material": t[46] / float(total)}
+                                "hit_row_normal_and_material": t[46] / float(total),
+                                "analytic_objects_and_the_rest": t[31] / float(total)}
     if t[28]:
         out["shadow_rounds"] = {"rounds": t[28], "lanes_walking_per_round": t[29] / float(t[28])}
     print(json.dumps(out, indent=1))

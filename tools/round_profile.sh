@@ -11,10 +11,10 @@ mkdir -p "$OUT"
 cd "$R"
 timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > "$OUT/gpu_tests.log" 2>&1 || { tail -5 "$OUT/gpu_tests.log"; exit 1; }
 tail -1 "$OUT/gpu_tests.log"
-timeout -k 10 400 python bench.py --steps 5 --save-pmc > "$OUT/bench_line.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
+timeout -k 10 400 python bench.py --save-pmc > "$OUT/bench_line.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
 cp profiles/pmc_dragon_1080p_16spp_ao_arealight.json "$OUT/pmc.json"
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 "$R/bench.py" --steps 5 --no-pmc --no-cpu-baseline > "$OUT/bench_line_profiled.json" 2> "$OUT/kt.err" || { tail -5 "$OUT/kt.err"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 "$R/bench.py" --no-pmc --no-cpu-baseline > "$OUT/bench_line_profiled.json" 2> "$OUT/kt.err" || { tail -5 "$OUT/kt.err"; exit 1; }
 find "$OUT/kt" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 rm -rf "$OUT/kt"
 cd "$R"
