@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 5
+#define RTAMD_ABI_VERSION 6
 
 enum {
     RTAMD_OK = 0,
@@ -295,8 +295,8 @@ typedef struct rtamd_scene_desc {
                                            elsewhere): what a lane reads when it sorts out which
                                            chunks of a leaf its own shadow ray can touch.  NULL:
                                            the wave tests the chunk boxes of one ray at a time */
-    const float *leaf_aabb;             /* device, optional: [n_kd_nodes][8] floats = for a leaf of at
-                                           most 64 rows the box around its triangles, lo.xyz
+    const float *leaf_aabb;             /* device, optional: [n_kd_nodes][8] floats = for every leaf
+                                           that holds rows the box around its triangles, lo.xyz
                                            hi.xyz and two unused (conservative, rounded
                                            outward); zeros for other nodes.  A ray that crosses
                                            the leaf's cell but misses this box skips the leaf */

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(HERE, "csrc", "librtamd.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_BRANCH_LEVELS = 8
 N_COUNTERS = 16
 COUNT_WORK = 1

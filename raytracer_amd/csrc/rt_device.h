@@ -512,8 +512,7 @@ __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& 
 //
 // The query runs in rounds.  In a round each lane walks the tree front to back exactly as
 // KDTree.iterate_nodes does (kdtree.py:133-155), with a stack of its own, until it stands at
-// a leaf it has to test (a leaf of up to 64 rows whose triangles' box the ray misses is
-// passed by); then the leaves are tested:
+// a leaf it has to test (a leaf whose triangles' box the ray misses is passed by); then the leaves are tested:
 //   * rays of a tile that have not bounced yet (`coherent`) reach the same leaves, so each
 //     lane scans its own leaf from the row-major table, big leaves through their boxes;
 //   * otherwise the wave tests the leaves together with coalesced loads of the
@@ -710,9 +709,9 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                 count = nd.b >> 2;
                 cbase = S.chunk_boxes ? (int32_t)nd.split : -1;
 #ifndef RT_NO_LEAF_AABB
-                // a leaf of up to 64 rows whose triangles' box the ray misses holds no hit: the
-                // lane walks on at once (not when counting: the reference tests the rows)
-                if (COUNT != 1 && use_leaf_aabb && count <= 64) {
+                // a leaf whose triangles' box the ray misses holds no hit: the lane walks on at
+                // once (not when counting: the reference tests the rows)
+                if (COUNT != 1 && use_leaf_aabb) {
                     double tn;
                     double tf;
                     if (count != 0) w.x_box(32);

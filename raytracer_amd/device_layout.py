@@ -127,12 +127,13 @@ def device_arrays(flat):
         glo, ghi = _boxes_f32(chunk_tree[has_group, 6:9], chunk_tree[has_group, 9:12])
         ct32[has_group, 6:9], ct32[has_group, 9:12] = glo, ghi
     a["chunk_tree"] = ct32.ravel()
-    # box around the triangles of every leaf of at most CHUNK rows (bigger leaves have chunk boxes)
+    # box around the triangles of every leaf (bigger leaves have chunk boxes as well)
     leaf_aabb = numpy.zeros((len(nodes), 6))
-    small = leaves[(counts > 0) & (counts <= CHUNK)]
+    boxed = counts > 0
+    small = leaves[boxed]
     if len(small):
         first = nodes["a"][small].astype(numpy.int64)
-        cnt = counts[(counts > 0) & (counts <= CHUNK)].astype(numpy.int64)
+        cnt = counts[boxed].astype(numpy.int64)
         row = numpy.repeat(first, cnt) + (numpy.arange(cnt.sum()) - numpy.repeat(numpy.cumsum(cnt) - cnt, cnt))
         seg = numpy.cumsum(cnt) - cnt
         v0 = geom[0:3, row]
