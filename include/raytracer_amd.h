@@ -297,9 +297,17 @@ typedef struct rtamd_scene_desc {
                                            the wave tests the chunk boxes of one ray at a time */
     const float *leaf_aabb;             /* device, optional: [n_kd_nodes][8] floats = for every leaf
                                            that holds rows the box around its triangles, lo.xyz
-                                           hi.xyz and two unused (conservative, rounded
-                                           outward); zeros for other nodes.  A ray that crosses
-                                           the leaf's cell but misses this box skips the leaf */
+                                           hi.xyz, then one int32 and one unused float
+                                           (conservative, rounded outward); zeros for other
+                                           nodes.  A ray that crosses the leaf's cell but misses
+                                           this box skips the leaf.  The int32, when > 0, is the
+                                           index in kd_nodes / kd_triples of the root of a
+                                           kd-tree over this leaf's triangles alone (nodes past
+                                           the trees proper, leaves of rows appended to the
+                                           triangle tables, each with a box row of its own):
+                                           shadow queries that any hit decides walk on into
+                                           it instead of testing the leaf.  rtamd_tree.depth
+                                           must then count the levels such a walk can pass */
     const rtamd_transform *transforms;  /* device, NULL when n_transforms == 0: inner levels of nested
                                            Instances */
 } rtamd_scene_desc;

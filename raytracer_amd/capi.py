@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(HERE, "csrc", "librtamd.s
 
 ABI_VERSION = 6
 MAX_BRANCH_LEVELS = 8
+MAX_TREE_DEPTH = 38           # levels a walk may pass through (the kernels' stack holds 40 entries)
 N_COUNTERS = 16
 COUNT_WORK = 1
 COUNT_EXECUTED = 2

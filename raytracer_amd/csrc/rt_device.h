@@ -715,7 +715,9 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                     double tn;
                     double tf;
                     if (count != 0) w.x_box(32);
-                    if (count == 0 || !box_touch_f(S.leaf_aabb + (int64_t)node * 8, r, inv_d, tn, tf)) {
+                    const f4* box = reinterpret_cast<const f4*>(S.leaf_aabb + (int64_t)node * 8);
+                    const f4 box_a = box[0], box_b = box[1];
+                    if (count == 0 || !box_touch6(box_a.x, box_a.y, box_a.z, box_a.w, box_b.x, box_b.y, r, inv_d, tn, tf)) {
                         w.x_skip();
                         if (sp == sb) { walking = false; first = 0; count = 0; cbase = -1; break; }
                         pop();
@@ -725,6 +727,18 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
                         if (STEAL && ++skips >= RT_MAX_SKIPS) { parked = true; break; }
                         continue;
                     }
+#ifndef RT_NO_SHADOW_SUBTREES
+                    // a query that any hit decides walks on into the leaf's own subtree, if it has
+                    // one (the root's index rides in the box row): small leaves with tight boxes
+                    // instead of hundreds of rows
+                    if (STEAL && steal_ok) {
+                        const int32_t sub = __float_as_int(box_b.z);
+                        if (sub > 0) {
+                            node = sub;
+                            continue;
+                        }
+                    }
+#endif
                 }
 #endif
                 break;

@@ -22,6 +22,7 @@ chunks there changes no result, because a triangle the exact test accepts has it
 point inside its own (padded) bounding box.
 """
 import ctypes as C
+import os
 
 import numpy
 
@@ -31,6 +32,7 @@ CHUNK = 64
 CELL = 8
 GROUP = 4           # chunks per group box in `chunk_tree`
 PAD = 1.0e-9
+SHADOW_SUBTREES = not os.environ.get("RTAMD_NO_SHADOW_SUBTREES")
 
 
 def _padded(lo, hi):
@@ -54,6 +56,74 @@ def _morton_order(centroids):
         for axis in range(3):
             code |= ((q[:, axis] >> bit) & 1) << (3 * bit + axis)
     return numpy.argsort(code, kind="stable")
+
+
+AUX_MIN_ROWS = CHUNK  # leaves of more rows than this get a shadow subtree
+AUX_LEAF = 16       # rows at which a shadow subtree stops splitting
+AUX_MAX_LEAF = 64   # a shadow subtree whose build leaves more rows than this in a leaf is dropped
+AUX_DEPTH = 16      # levels a shadow subtree may have (fewer below a deep leaf)
+
+
+def _shadow_subtree(lo, hi, max_depth):
+    """A kd-tree of its own over the (padded) boxes lo, hi [n, 3] of one big leaf's triangles,
+    for queries that any hit decides: surface-area heuristic over the box faces, triangles
+    whose box straddles a plane go to both sides.  Returns (records, leaves): records in
+    preorder as (axis, split, index of the right child) or (-1, leaf number, 0), and the row
+    numbers (into lo / hi) of every leaf, and the levels it has; None when some leaf would keep
+    more than AUX_MAX_LEAF rows within max_depth levels."""
+    records, leaves, reached = [], [], [0]
+
+    def area(d):
+        return d[0] * d[1] + d[1] * d[2] + d[2] * d[0]
+
+    def build(idx, cell_lo, cell_hi, depth):
+        n = len(idx)
+        me = len(records)
+        best = None
+        reached[0] = max(reached[0], depth)
+        if n > AUX_LEAF and depth < max_depth:
+            whole = area(cell_hi - cell_lo)
+            for axis in range(3):
+                l, h = lo[idx, axis], hi[idx, axis]
+                cand = numpy.unique(numpy.concatenate([l, h]))
+                cand = cand[(cand > cell_lo[axis]) & (cand < cell_hi[axis])]
+                if not len(cand):
+                    continue
+                n_left = numpy.searchsorted(numpy.sort(l), cand, side="left")          # boxes with lo < plane
+                n_right = n - numpy.searchsorted(numpy.sort(h), cand, side="right")     # boxes with hi > plane
+                d = cell_hi - cell_lo
+                dl, dr = numpy.tile(d, (len(cand), 1)), numpy.tile(d, (len(cand), 1))
+                dl[:, axis] = cand - cell_lo[axis]
+                dr[:, axis] = cell_hi[axis] - cand
+                al = dl[:, 0] * dl[:, 1] + dl[:, 1] * dl[:, 2] + dl[:, 2] * dl[:, 0]
+                ar = dr[:, 0] * dr[:, 1] + dr[:, 1] * dr[:, 2] + dr[:, 2] * dr[:, 0]
+                cost = 1.0 + (al * n_left + ar * n_right) / max(whole, 1e-300)
+                cost[(n_left == n) & (n_right == n)] = numpy.inf
+                k = int(numpy.argmin(cost))
+                if numpy.isfinite(cost[k]) and (best is None or cost[k] < best[0]):
+                    best = (float(cost[k]), axis, float(cand[k]))
+        if best is None or (best[0] >= n and n <= AUX_MAX_LEAF):
+            if n > AUX_MAX_LEAF:
+                raise OverflowError
+            records.append((-1, len(leaves), 0))
+            leaves.append(idx)
+            return
+        _, axis, plane = best
+        records.append(None)
+        left, right = idx[lo[idx, axis] < plane], idx[hi[idx, axis] > plane]
+        lh, rl = cell_hi.copy(), cell_lo.copy()
+        lh[axis] = plane
+        rl[axis] = plane
+        build(left, cell_lo, lh, depth + 1)
+        right_at = len(records)
+        build(right, rl, cell_hi, depth + 1)
+        records[me] = (axis, plane, right_at)
+
+    try:
+        build(numpy.arange(len(lo)), lo.min(axis=0), hi.max(axis=0), 0)
+    except OverflowError:
+        return None
+    return records, leaves, reached[0]
 
 
 def device_arrays(flat):
@@ -144,6 +214,68 @@ def device_arrays(flat):
     la32 = numpy.zeros((len(nodes), 8), dtype=numpy.float32)
     if len(small):
         la32[small, 0:3], la32[small, 3:6] = _boxes_f32(leaf_aabb[small, 0:3], leaf_aabb[small, 3:6])
+    # Shadow subtrees.  A shadow query that any hit decides (no limit, or the ray leaves the tree's
+    # box before its limit) only asks whether some triangle on the ray is hit, whichever leaf
+    # lists it.  For such rays every leaf of more than CHUNK rows gets a kd-tree of its own over
+    # its triangles (appended nodes, leaves of a few appended rows with tight boxes) that the
+    # walk continues into; its root's index rides in the seventh float of the leaf's box row.
+    trees = numpy.frombuffer(bytes(a["trees"]), dtype=numpy.uint8).copy()
+    tree_recs = (capi.Tree * (len(trees) // C.sizeof(capi.Tree))).from_buffer(trees)
+    tree_starts = numpy.array([t.node_offset for t in tree_recs], dtype=numpy.int64)
+    big = leaves[counts > AUX_MIN_ROWS]
+    if SHADOW_SUBTREES and len(tree_recs) and len(big):
+        # interior nodes above every node (children follow their parent in the array)
+        level = numpy.zeros(len(nodes), dtype=numpy.int64)
+        for i in numpy.nonzero((nodes["b"] & 3) != 3)[0]:
+            level[i + 1] = level[nodes["a"][i]] = level[i] + 1
+        extra_nodes, extra_rows, extra_boxes = [], [], []
+        next_node, next_row = len(nodes), n_refs
+        for node, count in zip(big, counts[counts > AUX_MIN_ROWS]):
+            tree = int(numpy.searchsorted(tree_starts, node, side="right")) - 1
+            room = min(AUX_DEPTH, capi.MAX_TREE_DEPTH - int(level[node]))
+            if room < 1:
+                continue
+            first = int(nodes["a"][node])
+            g = geom[:, first:first + int(count)]
+            v0, v1, v2 = g[0:3].T, (g[0:3] + g[3:6]).T, (g[0:3] + g[6:9]).T
+            blo, bhi = _padded(numpy.minimum(numpy.minimum(v0, v1), v2), numpy.maximum(numpy.maximum(v0, v1), v2))
+            built = _shadow_subtree(blo, bhi, room)
+            if built is None:
+                continue
+            records, sub_leaves, levels = built
+            # what a walk may now pass through
+            tree_recs[tree].depth = max(tree_recs[tree].depth, int(level[node]) + levels)
+            la32[node, 6] = numpy.array([next_node], dtype=numpy.int32).view(numpy.float32)[0]
+            for rec in records:
+                box = numpy.zeros(8, dtype=numpy.float32)
+                if rec[0] < 0:
+                    rows_here = sub_leaves[rec[1]]
+                    extra_nodes.append((-1.0, next_row, (len(rows_here) << 2) | 3))
+                    if len(rows_here):
+                        l32, h32 = _boxes_f32(blo[rows_here].min(axis=0)[None, :], bhi[rows_here].max(axis=0)[None, :])
+                        box[0:3], box[3:6] = l32[0], h32[0]
+                    extra_rows.append(first + rows_here)
+                    next_row += len(rows_here)
+                else:
+                    extra_nodes.append((rec[1], next_node + rec[2], rec[0]))
+                extra_boxes.append(box)
+            next_node += len(records)
+        if extra_nodes:
+            more = numpy.array(extra_nodes, dtype=nodes.dtype)
+            nodes = numpy.concatenate([nodes, more])
+            la32 = numpy.concatenate([la32, numpy.array(extra_boxes, dtype=numpy.float32)])
+            src = numpy.concatenate(extra_rows) if extra_rows else numpy.zeros(0, dtype=numpy.int64)
+            geom = numpy.concatenate([geom, geom[:, src]], axis=1)
+            prim = numpy.concatenate([prim, prim[src]])
+            order = numpy.concatenate([order, order[src]])
+            a["tri_geom"] = numpy.ascontiguousarray(geom).ravel()
+            a["tri_prim"] = prim
+            a["tri_order"] = order
+            rows = numpy.zeros((len(prim), 10))
+            rows[:, :9] = geom.T
+            rows[:, 9] = numpy.stack([prim.astype(numpy.int32), order], axis=1).copy().view(numpy.float64)[:, 0]
+            a["tri_rows"] = rows.ravel()
+            a["trees"] = trees
     a["leaf_aabb"] = la32.ravel()
     a["kd_nodes"] = nodes.view(numpy.uint8)
     # node, left child, right child side by side: two levels of the walk per load

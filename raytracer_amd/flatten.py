@@ -22,7 +22,7 @@ import material as M
 import sampler as S
 import tracer as T
 
-MAX_TREE_DEPTH = 60           # traversal stack bound compiled into the kernels
+MAX_TREE_DEPTH = capi.MAX_TREE_DEPTH + 2      # traversal stack bound compiled into the kernels
 NO_SHADOW_BIT = 1 << 30
 
 
@@ -243,7 +243,9 @@ class _Flattener(object):
         if isinstance(target, K.KDTree):
             o.kind = capi.KDTREE
             o.tree = self.add_tree(target)
-            o.cast_shadow = int(bool(target.cast_shadow))
+            # KDTree.shadow_hit has no cast_shadow test of its own (kdtree.py:157-164): a flag set
+            # on the tree object changes nothing, only its triangles' flags count
+            o.cast_shadow = 1
             return o
         rec = target.device_record()
         o.kind = rec["kind"]

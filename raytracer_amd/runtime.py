@@ -44,6 +44,8 @@ class DeviceScene(object):
         self.tensors = {}
         with torch.cuda.device(self.device):
             arrays, n_chunks = device_layout.device_arrays(self.flat)
+            self.n_kd_nodes = len(arrays["kd_nodes"]) // C.sizeof(capi.KdNode)
+            self.n_refs = len(arrays["tri_prim"])
             for name, arr in arrays.items():
                 host = torch.from_numpy(numpy.ascontiguousarray(arr).view(numpy.uint8).reshape(-1).copy())
                 if host.numel() == 0:
@@ -58,12 +60,19 @@ class DeviceScene(object):
             desc.chunk_tree = self.tensors["chunk_tree"].data_ptr()
             desc.leaf_aabb = self.tensors["leaf_aabb"].data_ptr()
             desc.n_chunks = n_chunks
+            self.table_sizes(desc)
             handle = C.c_void_p()
             # the library reads the small tables back on the null stream: the uploads must have landed
             torch.cuda.current_stream(self.device).synchronize()
             capi.check(self.lib.rtamd_scene_create(C.byref(desc), C.byref(handle)), self.lib)
         self.handle = handle
         self.counters = torch.zeros(capi.N_COUNTERS, dtype=torch.int64, device=self.device)
+
+    def table_sizes(self, desc):
+        """Node and row counts of the device tables, which may hold appended nodes and rows
+        (shadow subtrees of big leaves) beyond the canonical ones."""
+        desc.n_kd_nodes, desc.n_refs = self.n_kd_nodes, self.n_refs
+        return desc
 
     def close(self):
         if getattr(self, "handle", None):

@@ -456,7 +456,7 @@ def test_optional_device_tables_may_be_absent(torch_gpu, tables):
         desc.kd_triples = ds.tensors["kd_triples"].data_ptr()   # node records do not depend on the row order...
         # ...except a leaf's chunk index, which is only read when chunk_boxes is given
     else:
-        desc = ds.flat.desc(lambda name, arr: ds.tensors[name].data_ptr())
+        desc = ds.table_sizes(ds.flat.desc(lambda name, arr: ds.tensors[name].data_ptr()))
         desc.kd_triples = ds.tensors["kd_triples"].data_ptr()
         desc.tri_order = ds.tensors["tri_order"].data_ptr()
         desc.chunk_boxes = ds.tensors["chunk_boxes"].data_ptr()

@@ -115,13 +115,18 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
     flat = common.flat_for(scene)
     dev, n_chunks = device_layout.device_arrays(flat)
     n = len(flat.arrays["tri_prim"])
+    n_all = len(dev["tri_prim"])                      # rows of shadow subtrees are appended
+    n_nodes = len(flat.arrays["kd_nodes"]) // 16
     canon = flat.arrays["tri_geom"].reshape(9, n)
-    geom = dev["tri_geom"].reshape(9, n)
-    order = dev["tri_order"]
+    geom_all = dev["tri_geom"].reshape(9, n_all)
+    geom = geom_all[:, :n]
+    order_all = dev["tri_order"]
+    order = order_all[:n]
     assert numpy.array_equal(numpy.sort(order), numpy.arange(n))
     assert numpy.array_equal(geom, canon[:, order])
-    assert numpy.array_equal(dev["tri_prim"], flat.arrays["tri_prim"][order])
-    nodes = dev["kd_nodes"].view([("split", "<f8"), ("a", "<i4"), ("b", "<i4")])
+    assert numpy.array_equal(dev["tri_prim"][:n], flat.arrays["tri_prim"][order])
+    nodes_all = dev["kd_nodes"].view([("split", "<f8"), ("a", "<i4"), ("b", "<i4")])
+    nodes = nodes_all[:n_nodes]
     boxes = dev["chunk_boxes"].reshape(6, n_chunks)
     leaf_boxes = dev["leaf_boxes"].reshape(n_chunks, 9, 6)
     chunk_tree = dev["chunk_tree"].reshape(n_chunks, 12).astype(numpy.float64)
@@ -129,12 +134,13 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
     # single-precision copies enclose the double boxes and stay close to them
     assert (chunk_tree[:, 0:3].T <= boxes[0:3]).all() and (chunk_tree[:, 3:6].T >= boxes[3:6]).all()
     assert numpy.allclose(chunk_tree[:, :6].T, boxes, rtol=2e-7, atol=1e-30)
-    rows_aos = dev["tri_rows"].reshape(n, 10)
-    assert numpy.array_equal(rows_aos[:, :9], geom.T)
-    meta = numpy.ascontiguousarray(rows_aos[:, 9]).view(numpy.int32).reshape(n, 2)
-    assert numpy.array_equal(meta[:, 0], dev["tri_prim"]) and numpy.array_equal(meta[:, 1], order)
+    rows_aos = dev["tri_rows"].reshape(n_all, 10)
+    assert numpy.array_equal(rows_aos[:, :9], geom_all.T)
+    meta = numpy.ascontiguousarray(rows_aos[:, 9]).view(numpy.int32).reshape(n_all, 2)
+    assert numpy.array_equal(meta[:, 0], dev["tri_prim"]) and numpy.array_equal(meta[:, 1], order_all)
+    check_shadow_subtrees(dev, nodes_all, n_nodes, geom_all, n)
     seen = 0
-    leaf_aabb = dev["leaf_aabb"].reshape(len(nodes), 8).astype(numpy.float64)[:, :6]
+    leaf_aabb = dev["leaf_aabb"].reshape(len(nodes_all), 8).astype(numpy.float64)[:n_nodes, :6]
     assert not leaf_aabb[(nodes["b"] & 3) != 3].any()
     for index in numpy.nonzero((nodes["b"] & 3) == 3)[0]:
         nd = nodes[index]
@@ -175,6 +181,53 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
                 assert (cp.min(axis=1) > kb[0:3]).all() and (cp.max(axis=1) < kb[3:6]).all()
             seen += 1
     assert seen == n_chunks and n_chunks > 0
+
+
+def check_shadow_subtrees(dev, nodes, n_nodes, geom, n_rows):
+    """Every leaf of more than 64 rows has a kd-tree of its own behind the seventh float of its
+    box row: a leaf of that tree holds every triangle of the big leaf whose (padded) box reaches
+    into the leaf's cell, as copies in appended rows, all inside the leaf's box."""
+    from raytracer_amd import device_layout
+    table = dev["leaf_aabb"].reshape(len(nodes), 8)
+    roots = table[:, 6].view(numpy.int32)
+    assert not roots[n_nodes:].any()
+    big = [i for i in range(n_nodes) if (nodes["b"][i] & 3) == 3 and (nodes["b"][i] >> 2) > device_layout.CHUNK]
+    assert len(big) and all(roots[i] >= n_nodes for i in big)
+    assert set(numpy.nonzero(roots)[0]) == set(big)
+    prim = dev["tri_prim"]
+    for leaf in big:
+        first, count = int(nodes["a"][leaf]), int(nodes["b"][leaf]) >> 2
+        g = geom[:, first:first + count]
+        v = numpy.stack([g[0:3], g[0:3] + g[3:6], g[0:3] + g[6:9]])
+        lo, hi = device_layout._padded(v.min(axis=0).T, v.max(axis=0).T)
+        todo = [(int(roots[leaf]), lo.min(axis=0), hi.max(axis=0), 0)]
+        seen = numpy.zeros(count, dtype=bool)
+        while todo:
+            at, cell_lo, cell_hi, level = todo.pop()
+            assert n_nodes <= at < len(nodes) and level <= device_layout.AUX_DEPTH
+            if (nodes["b"][at] & 3) == 3:
+                f, c = int(nodes["a"][at]), int(nodes["b"][at]) >> 2
+                assert f >= n_rows and c <= device_layout.AUX_MAX_LEAF and nodes["split"][at] < 0
+                inside = ((lo < cell_hi) & (hi > cell_lo)).all(axis=1)
+                # the rows of the leaf are copies of exactly those triangles
+                here = geom[:, f:f + c]
+                want = g[:, inside]
+                assert here.shape == want.shape
+                key = lambda m: sorted(map(bytes, numpy.ascontiguousarray(m.T)))
+                assert key(here) == key(want)
+                assert sorted(prim[f:f + c]) == sorted(prim[first:first + count][inside])
+                seen |= inside
+                if c:
+                    box = table[at, :6].astype(numpy.float64)
+                    assert (lo[inside].min(axis=0) >= box[0:3]).all() and (hi[inside].max(axis=0) <= box[3:6]).all()
+                continue
+            axis, plane, right = int(nodes["b"][at]), float(nodes["split"][at]), int(nodes["a"][at])
+            assert 0 <= axis < 3 and cell_lo[axis] < plane < cell_hi[axis] and right > at + 1
+            left_hi, right_lo = cell_hi.copy(), cell_lo.copy()
+            left_hi[axis] = right_lo[axis] = plane
+            todo.append((at + 1, cell_lo, left_hi, level + 1))
+            todo.append((right, right_lo, cell_hi, level + 1))
+        assert seen.all()
 
 
 def test_unsupported_scene_features_are_refused():
