@@ -198,11 +198,17 @@ typedef struct rtamd_tree {
     int32_t ref_offset;     /* first leaf reference of this tree in tri_* arrays   */
     int32_t prim_offset;    /* first primitive of this tree in prim_* arrays       */
     int32_t smooth;         /* vertex normals present: prim_normals holds 9/prim   */
-    int32_t depth;          /* maximum node depth (stack bound)                    */
+    int32_t depth;          /* maximum node depth (stack bound), shadow tree and shadow
+                               subtrees (leaf_aabb) included                       */
     int32_t shadow_casters; /* what bit 30 of this tree's tri_prim rows says, in one word:
                                RTAMD_CASTERS_ALL (no row has it), _NONE (every row has it:
                                a mesh with cast_shadow off, geometry.py:433-434) or _MIXED */
-    int32_t reserved[2];
+    int32_t shadow_root;    /* 0, or the index in kd_nodes / kd_triples (past the trees proper)
+                               of the root of another kd-tree over the same triangles, any
+                               shape, with leaf_aabb rows for its leaves: shadow queries that
+                               any hit decides (no limit, or the ray leaves bbox before its
+                               limit) walk this tree instead; needs leaf_aabb      */
+    int32_t reserved;
 } rtamd_tree;
 enum { RTAMD_CASTERS_ALL = 0, RTAMD_CASTERS_NONE = 1, RTAMD_CASTERS_MIXED = 2 };
 

@@ -66,7 +66,7 @@ class KdNode(C.Structure):
 class Tree(C.Structure):
     _fields_ = [("bbox_lo", d3), ("bbox_hi", d3), ("node_offset", C.c_int32),
                 ("ref_offset", C.c_int32), ("prim_offset", C.c_int32), ("smooth", C.c_int32),
-                ("depth", C.c_int32), ("shadow_casters", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("depth", C.c_int32), ("shadow_casters", C.c_int32), ("shadow_root", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Texture(C.Structure):

@@ -570,6 +570,11 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     bool out_found = false;
     double out_t = 0;
     bool steal_ok = STEAL && walking && (t_exit * (1.0 + 1e-9) + 1e-9 < limit);
+#ifndef RT_NO_SHADOW_SUBTREES
+    // Whether such a ray is occluded does not depend on which leaf lists the triangle it hits:
+    // it walks the tree's shadow tree (the same triangles in a kd-tree built for this walk)
+    if (STEAL && steal_ok && use_leaf_aabb && T.shadow_root > 0) node = T.shadow_root;
+#endif
     PhaseClock clk;
     clk.start(SHADOW ? (limit_in > T_INF ? 36 : 8) : 0);     // shadow queries without a limit (ambient occlusion) apart
     clk.count(PH_QUERIES);

@@ -58,50 +58,48 @@ def _morton_order(centroids):
     return numpy.argsort(code, kind="stable")
 
 
+SHADOW_TREE_MIN_ROWS = 512      # trees with at least this many rows get a shadow tree of their own
 AUX_MIN_ROWS = CHUNK  # leaves of more rows than this get a shadow subtree
 AUX_LEAF = 16       # rows at which a shadow subtree stops splitting
 AUX_MAX_LEAF = 64   # a shadow subtree whose build leaves more rows than this in a leaf is dropped
+AUX_STEP_COST = 1.0  # cost of a traversal step in triangle tests
 AUX_DEPTH = 16      # levels a shadow subtree may have (fewer below a deep leaf)
 
 
 def _shadow_subtree(lo, hi, max_depth):
-    """A kd-tree of its own over the (padded) boxes lo, hi [n, 3] of one big leaf's triangles,
-    for queries that any hit decides: surface-area heuristic over the box faces, triangles
-    whose box straddles a plane go to both sides.  Returns (records, leaves): records in
-    preorder as (axis, split, index of the right child) or (-1, leaf number, 0), and the row
-    numbers (into lo / hi) of every leaf, and the levels it has; None when some leaf would keep
-    more than AUX_MAX_LEAF rows within max_depth levels."""
+    """A kd-tree over the (padded) triangle boxes lo, hi [n, 3], for queries that any hit
+    decides: surface-area heuristic over the box faces, triangles whose box straddles a plane
+    go to both sides.  Returns (records, leaves, levels): records in preorder as (axis, split,
+    index of the right child) or (-1, leaf number, 0), and the row numbers (into lo / hi) of
+    every leaf; None when some leaf would keep more than AUX_MAX_LEAF rows within max_depth
+    levels."""
     records, leaves, reached = [], [], [0]
-
-    def area(d):
-        return d[0] * d[1] + d[1] * d[2] + d[2] * d[0]
+    inf = numpy.inf
 
     def build(idx, cell_lo, cell_hi, depth):
         n = len(idx)
         me = len(records)
         best = None
-        reached[0] = max(reached[0], depth)
+        if depth > reached[0]:
+            reached[0] = depth
         if n > AUX_LEAF and depth < max_depth:
-            whole = area(cell_hi - cell_lo)
+            l, h = lo[idx], hi[idx]
+            cand = numpy.concatenate([l, h])
+            sorted_lo, sorted_hi = numpy.sort(l, axis=0), numpy.sort(h, axis=0)
+            d = cell_hi - cell_lo
+            whole = max(d[0] * d[1] + d[1] * d[2] + d[2] * d[0], 1e-300)
             for axis in range(3):
-                l, h = lo[idx, axis], hi[idx, axis]
-                cand = numpy.unique(numpy.concatenate([l, h]))
-                cand = cand[(cand > cell_lo[axis]) & (cand < cell_hi[axis])]
-                if not len(cand):
-                    continue
-                n_left = numpy.searchsorted(numpy.sort(l), cand, side="left")          # boxes with lo < plane
-                n_right = n - numpy.searchsorted(numpy.sort(h), cand, side="right")     # boxes with hi > plane
-                d = cell_hi - cell_lo
-                dl, dr = numpy.tile(d, (len(cand), 1)), numpy.tile(d, (len(cand), 1))
-                dl[:, axis] = cand - cell_lo[axis]
-                dr[:, axis] = cell_hi[axis] - cand
-                al = dl[:, 0] * dl[:, 1] + dl[:, 1] * dl[:, 2] + dl[:, 2] * dl[:, 0]
-                ar = dr[:, 0] * dr[:, 1] + dr[:, 1] * dr[:, 2] + dr[:, 2] * dr[:, 0]
-                cost = 1.0 + (al * n_left + ar * n_right) / max(whole, 1e-300)
-                cost[(n_left == n) & (n_right == n)] = numpy.inf
+                c = cand[:, axis]
+                n_left = numpy.searchsorted(sorted_lo[:, axis], c, side="left")         # boxes with lo < plane
+                n_right = n - numpy.searchsorted(sorted_hi[:, axis], c, side="right")    # boxes with hi > plane
+                d1, d2 = d[(axis + 1) % 3], d[(axis + 2) % 3]
+                # surface of a box that is x long on this axis: x * (d1 + d2) + d1 * d2
+                cost = AUX_STEP_COST + (((c - cell_lo[axis]) * (d1 + d2) + d1 * d2) * n_left
+                                        + ((cell_hi[axis] - c) * (d1 + d2) + d1 * d2) * n_right) / whole
+                cost[(c <= cell_lo[axis]) | (c >= cell_hi[axis]) | ((n_left == n) & (n_right == n))] = inf
                 k = int(numpy.argmin(cost))
-                if numpy.isfinite(cost[k]) and (best is None or cost[k] < best[0]):
-                    best = (float(cost[k]), axis, float(cand[k]))
+                if cost[k] < (inf if best is None else best[0]):
+                    best = (float(cost[k]), axis, float(c[k]))
         if best is None or (best[0] >= n and n <= AUX_MAX_LEAF):
             if n > AUX_MAX_LEAF:
                 raise OverflowError
@@ -127,6 +125,15 @@ def _shadow_subtree(lo, hi, max_depth):
 
 
 def device_arrays(flat):
+    """Tables to upload (see _device_arrays), worked out once per flat scene."""
+    key = (SHADOW_SUBTREES, SHADOW_TREE_MIN_ROWS)
+    cached = getattr(flat, "_device_arrays", None)
+    if cached is None or cached[0] != key:
+        cached = flat._device_arrays = (key,) + _device_arrays(flat)
+    return dict(cached[1]), cached[2]
+
+
+def _device_arrays(flat):
     """Tables to upload: the canonical ones, with big leaves re-arranged, plus
     `tri_order` (int32 per row) and `chunk_boxes` (SoA [6][n_chunks]: lo xyz, hi xyz)."""
     a = dict(flat.arrays)
@@ -223,43 +230,69 @@ def device_arrays(flat):
     tree_recs = (capi.Tree * (len(trees) // C.sizeof(capi.Tree))).from_buffer(trees)
     tree_starts = numpy.array([t.node_offset for t in tree_recs], dtype=numpy.int64)
     big = leaves[counts > AUX_MIN_ROWS]
-    if SHADOW_SUBTREES and len(tree_recs) and len(big):
+    if SHADOW_SUBTREES and len(tree_recs):
         # interior nodes above every node (children follow their parent in the array)
         level = numpy.zeros(len(nodes), dtype=numpy.int64)
         for i in numpy.nonzero((nodes["b"] & 3) != 3)[0]:
             level[i + 1] = level[nodes["a"][i]] = level[i] + 1
         extra_nodes, extra_rows, extra_boxes = [], [], []
-        next_node, next_row = len(nodes), n_refs
-        for node, count in zip(big, counts[counts > AUX_MIN_ROWS]):
-            tree = int(numpy.searchsorted(tree_starts, node, side="right")) - 1
-            room = min(AUX_DEPTH, capi.MAX_TREE_DEPTH - int(level[node]))
-            if room < 1:
-                continue
-            first = int(nodes["a"][node])
-            g = geom[:, first:first + int(count)]
+        next_node, next_row = [len(nodes)], [n_refs]
+
+        def attach(src_rows, room):
+            """Build a shadow subtree over the table rows src_rows; (root index, levels) or None."""
+            g = geom[:, src_rows]
             v0, v1, v2 = g[0:3].T, (g[0:3] + g[3:6]).T, (g[0:3] + g[6:9]).T
             blo, bhi = _padded(numpy.minimum(numpy.minimum(v0, v1), v2), numpy.maximum(numpy.maximum(v0, v1), v2))
             built = _shadow_subtree(blo, bhi, room)
             if built is None:
-                continue
+                return None
             records, sub_leaves, levels = built
-            # what a walk may now pass through
-            tree_recs[tree].depth = max(tree_recs[tree].depth, int(level[node]) + levels)
-            la32[node, 6] = numpy.array([next_node], dtype=numpy.int32).view(numpy.float32)[0]
+            root = next_node[0]
             for rec in records:
                 box = numpy.zeros(8, dtype=numpy.float32)
                 if rec[0] < 0:
                     rows_here = sub_leaves[rec[1]]
-                    extra_nodes.append((-1.0, next_row, (len(rows_here) << 2) | 3))
+                    extra_nodes.append((-1.0, next_row[0], (len(rows_here) << 2) | 3))
                     if len(rows_here):
                         l32, h32 = _boxes_f32(blo[rows_here].min(axis=0)[None, :], bhi[rows_here].max(axis=0)[None, :])
                         box[0:3], box[3:6] = l32[0], h32[0]
-                    extra_rows.append(first + rows_here)
-                    next_row += len(rows_here)
+                    extra_rows.append(src_rows[rows_here])
+                    next_row[0] += len(rows_here)
                 else:
-                    extra_nodes.append((rec[1], next_node + rec[2], rec[0]))
+                    extra_nodes.append((rec[1], root + rec[2], rec[0]))
                 extra_boxes.append(box)
-            next_node += len(records)
+            next_node[0] += len(records)
+            return root, levels
+
+        whole = set()
+        ref_starts = [t.ref_offset for t in tree_recs] + [n_refs]
+        for ti, t in enumerate(tree_recs):
+            lo_r, hi_r = ref_starts[ti], ref_starts[ti + 1]
+            if hi_r - lo_r < SHADOW_TREE_MIN_ROWS:
+                continue
+            # every triangle of the tree once; those that cast no shadow (bit 30) cannot occlude
+            ids = prim[lo_r:hi_r]
+            _, firsts = numpy.unique(ids, return_index=True)
+            firsts = numpy.sort(firsts[(ids[firsts] & (1 << 30)) == 0])
+            if not len(firsts):
+                continue
+            got = attach(lo_r + firsts, capi.MAX_TREE_DEPTH)
+            if got is not None:
+                t.shadow_root = got[0]
+                t.depth = max(t.depth, got[1])
+                whole.add(ti)
+        for node, count in zip(big, counts[counts > AUX_MIN_ROWS]):
+            tree = int(numpy.searchsorted(tree_starts, node, side="right")) - 1
+            room = min(AUX_DEPTH, capi.MAX_TREE_DEPTH - int(level[node]))
+            if room < 1 or tree in whole:
+                continue
+            first = int(nodes["a"][node])
+            got = attach(numpy.arange(first, first + int(count)), room)
+            if got is None:
+                continue
+            # what a walk may now pass through
+            tree_recs[tree].depth = max(tree_recs[tree].depth, int(level[node]) + got[1])
+            la32[node, 6] = numpy.array([got[0]], dtype=numpy.int32).view(numpy.float32)[0]
         if extra_nodes:
             more = numpy.array(extra_nodes, dtype=nodes.dtype)
             nodes = numpy.concatenate([nodes, more])

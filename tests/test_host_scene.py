@@ -107,12 +107,14 @@ def test_struct_layouts_match_the_header(repo_root):
     assert sizes == [C.sizeof(k) for k in classes]
 
 
-@pytest.mark.parametrize("scene", ("features_mesh", "j"))
-def test_device_layout_is_a_conservative_rearrangement(scene):
+@pytest.mark.parametrize("scene,whole_trees", (("features_mesh", True), ("j", True), ("j", False)))
+def test_device_layout_is_a_conservative_rearrangement(scene, whole_trees, monkeypatch):
     """Big leaves: rows permuted within the leaf only, tri_order records the scan position,
     every triangle lies inside the box of its 64-row chunk."""
     from raytracer_amd import device_layout
     flat = common.flat_for(scene)
+    if not whole_trees:
+        monkeypatch.setattr(device_layout, "SHADOW_TREE_MIN_ROWS", 1 << 40)
     dev, n_chunks = device_layout.device_arrays(flat)
     n = len(flat.arrays["tri_prim"])
     n_all = len(dev["tri_prim"])                      # rows of shadow subtrees are appended
@@ -138,7 +140,7 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
     assert numpy.array_equal(rows_aos[:, :9], geom_all.T)
     meta = numpy.ascontiguousarray(rows_aos[:, 9]).view(numpy.int32).reshape(n_all, 2)
     assert numpy.array_equal(meta[:, 0], dev["tri_prim"]) and numpy.array_equal(meta[:, 1], order_all)
-    check_shadow_subtrees(dev, nodes_all, n_nodes, geom_all, n)
+    check_shadow_subtrees(dev, nodes_all, n_nodes, geom_all, n, whole_trees)
     seen = 0
     leaf_aabb = dev["leaf_aabb"].reshape(len(nodes_all), 8).astype(numpy.float64)[:n_nodes, :6]
     assert not leaf_aabb[(nodes["b"] & 3) != 3].any()
@@ -183,50 +185,67 @@ def test_device_layout_is_a_conservative_rearrangement(scene):
     assert seen == n_chunks and n_chunks > 0
 
 
-def check_shadow_subtrees(dev, nodes, n_nodes, geom, n_rows):
-    """Every leaf of more than 64 rows has a kd-tree of its own behind the seventh float of its
-    box row: a leaf of that tree holds every triangle of the big leaf whose (padded) box reaches
-    into the leaf's cell, as copies in appended rows, all inside the leaf's box."""
-    from raytracer_amd import device_layout
+def check_shadow_subtrees(dev, nodes, n_nodes, geom, n_rows, whole_trees):
+    """Shadow trees: behind `shadow_root` of a tree a kd-tree over all its shadow-casting
+    triangles, or (when there is none) behind the seventh float of the box row of every leaf of
+    more than 64 rows a kd-tree over that leaf's triangles.  A leaf of such a tree holds every
+    triangle whose (padded) box reaches into the leaf's cell, as copies in appended rows, all
+    inside the leaf's box."""
+    import ctypes as C
+    from raytracer_amd import capi, device_layout
     table = dev["leaf_aabb"].reshape(len(nodes), 8)
     roots = table[:, 6].view(numpy.int32)
     assert not roots[n_nodes:].any()
-    big = [i for i in range(n_nodes) if (nodes["b"][i] & 3) == 3 and (nodes["b"][i] >> 2) > device_layout.CHUNK]
-    assert len(big) and all(roots[i] >= n_nodes for i in big)
-    assert set(numpy.nonzero(roots)[0]) == set(big)
     prim = dev["tri_prim"]
-    for leaf in big:
-        first, count = int(nodes["a"][leaf]), int(nodes["b"][leaf]) >> 2
-        g = geom[:, first:first + count]
+    raw = bytes(dev["trees"])
+    trees = (capi.Tree * (len(raw) // C.sizeof(capi.Tree))).from_buffer_copy(raw)
+    jobs = []
+    if whole_trees:
+        assert not roots.any()
+        ends = [t.ref_offset for t in trees][1:] + [n_rows]
+        for t, end in zip(trees, ends):
+            if end - t.ref_offset >= device_layout.SHADOW_TREE_MIN_ROWS:
+                assert t.shadow_root >= n_nodes
+                ids = prim[t.ref_offset:end]
+                _, firsts = numpy.unique(ids, return_index=True)
+                jobs.append((t.shadow_root, t.ref_offset + numpy.sort(firsts[(ids[firsts] >> 30) == 0]), capi.MAX_TREE_DEPTH))
+            else:
+                assert t.shadow_root == 0
+        assert jobs
+    else:
+        big = [i for i in range(n_nodes) if (nodes["b"][i] & 3) == 3 and (nodes["b"][i] >> 2) > device_layout.CHUNK]
+        assert len(big) and set(numpy.nonzero(roots)[0]) == set(big) and all(t.shadow_root == 0 for t in trees)
+        for leaf in big:
+            first, count = int(nodes["a"][leaf]), int(nodes["b"][leaf]) >> 2
+            jobs.append((int(roots[leaf]), numpy.arange(first, first + count), device_layout.AUX_DEPTH))
+    for root, src, max_levels in jobs:
+        g = geom[:, src]
         v = numpy.stack([g[0:3], g[0:3] + g[3:6], g[0:3] + g[6:9]])
         lo, hi = device_layout._padded(v.min(axis=0).T, v.max(axis=0).T)
-        todo = [(int(roots[leaf]), lo.min(axis=0), hi.max(axis=0), 0)]
-        seen = numpy.zeros(count, dtype=bool)
+        todo = [(root, lo.min(axis=0), hi.max(axis=0), 0, numpy.arange(len(src)))]
+        seen = numpy.zeros(len(src), dtype=bool)
         while todo:
-            at, cell_lo, cell_hi, level = todo.pop()
-            assert n_nodes <= at < len(nodes) and level <= device_layout.AUX_DEPTH
+            at, cell_lo, cell_hi, level, members = todo.pop()
+            assert n_nodes <= at < len(nodes) and level <= max_levels
             if (nodes["b"][at] & 3) == 3:
                 f, c = int(nodes["a"][at]), int(nodes["b"][at]) >> 2
                 assert f >= n_rows and c <= device_layout.AUX_MAX_LEAF and nodes["split"][at] < 0
-                inside = ((lo < cell_hi) & (hi > cell_lo)).all(axis=1)
-                # the rows of the leaf are copies of exactly those triangles
-                here = geom[:, f:f + c]
-                want = g[:, inside]
-                assert here.shape == want.shape
+                # the rows of the leaf are copies of exactly the triangles that reach into its cell
+                assert c == len(members)
                 key = lambda m: sorted(map(bytes, numpy.ascontiguousarray(m.T)))
-                assert key(here) == key(want)
-                assert sorted(prim[f:f + c]) == sorted(prim[first:first + count][inside])
-                seen |= inside
+                assert key(geom[:, f:f + c]) == key(g[:, members])
+                assert sorted(prim[f:f + c]) == sorted(prim[src[members]])
+                seen[members] = True
                 if c:
                     box = table[at, :6].astype(numpy.float64)
-                    assert (lo[inside].min(axis=0) >= box[0:3]).all() and (hi[inside].max(axis=0) <= box[3:6]).all()
+                    assert (lo[members].min(axis=0) >= box[0:3]).all() and (hi[members].max(axis=0) <= box[3:6]).all()
                 continue
             axis, plane, right = int(nodes["b"][at]), float(nodes["split"][at]), int(nodes["a"][at])
             assert 0 <= axis < 3 and cell_lo[axis] < plane < cell_hi[axis] and right > at + 1
             left_hi, right_lo = cell_hi.copy(), cell_lo.copy()
             left_hi[axis] = right_lo[axis] = plane
-            todo.append((at + 1, cell_lo, left_hi, level + 1))
-            todo.append((right, right_lo, cell_hi, level + 1))
+            todo.append((at + 1, cell_lo, left_hi, level + 1, members[lo[members, axis] < plane]))
+            todo.append((right, right_lo, cell_hi, level + 1, members[hi[members, axis] > plane]))
         assert seen.all()
 
 
