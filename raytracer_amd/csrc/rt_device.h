@@ -40,6 +40,7 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 }
 __device__ __forceinline__ double norm(V3 a) { return sqrt(dot(a, a)); }
 __device__ __forceinline__ double axis_of(V3 a, int ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z); }
+__device__ __forceinline__ float axis_of_f(float x, float y, float z, int ax) { return ax == 0 ? x : (ax == 1 ? y : z); }
 
 // Python's min/max keep the first argument unless a later one compares strictly
 // beyond it; with NaN operands that is not fmin/fmax.
@@ -508,6 +509,221 @@ __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& 
     }
 }
 
+// Shadow queries that any hit decides, on a tree's shadow tree (rtamd_tree::shadow_root).
+//
+// Such a query asks only whether some triangle is hit anywhere on the ray inside the tree's box:
+// neither the order of the leaves nor the leaf that lists the triangle matters, only that the
+// exact test runs on every triangle the ray can hit.  The walk is therefore free to be
+// approximate as long as it errs towards visiting: it runs in single precision (origin,
+// reciprocal direction, plane distances, interval bounds and leaf boxes), which halves the
+// registers and the instructions of a step.  What makes that safe is in the tree, not here: the
+// host lists a triangle in every leaf whose cell its box reaches into after widening the box
+// by far more (1e-5 of the scene's extent) than the walk's rounding can move a point
+// (about 1e-6 of it), and widens the leaf boxes by the same amount.  The triangle tests are
+// the exact double-precision ones.
+//
+// Rounds, short rounds, hand-over of the bottom stack entry to idle lanes and packed leaf steps
+// work as in kd_query_wave below.  A stack entry is (node, t at the plane as a float) in eight
+// bytes, the first LDS_STACK of every lane in the LDS array the double-precision walk keeps its
+// t values in.
+template <int COUNT>
+__device__ void shadow_tree_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool walking, const Ray& ray_in,
+                                 double near_in, double exit_in, bool unlimited, const KdStack& stk,
+                                 Work<COUNT>& w, bool& found, TriHit& best) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const int lane = lane_id();
+    Ray r = ray_in;                         // own ray, or the one whose walk this lane took over
+    float ox = (float)r.o.x, oy = (float)r.o.y, oz = (float)r.o.z;
+    auto reciprocal = [](double d) { return fminf(fmaxf(__builtin_amdgcn_rcpf((float)d), -3.0e37f), 3.0e37f); };
+    float ix = reciprocal(r.d.x), iy = reciprocal(r.d.y), iz = reciprocal(r.d.z);
+    float t_near = (float)near_in, t_far = (float)exit_in, t_exit = (float)exit_in;
+    u32x2* lds = reinterpret_cast<u32x2*>(stk.t);                   // [LDS_STACK][64] entries
+    u32x2 deep[STACK_MAX - LDS_STACK];
+    int sp = 0, sb = 0, owner = lane;
+    int32_t node = T.shadow_root;
+    bool out_found = false;
+    double out_t = 0;
+    found = false;
+    PhaseClock clk;
+    clk.start(unlimited ? 36 : 8);
+    clk.count(PH_QUERIES);
+
+    auto entry_at = [&](int i) -> u32x2 { return i < LDS_STACK ? lds[i * 64 + lane] : deep[i - LDS_STACK]; };
+    auto pop = [&]() {
+        sp--;
+        const u32x2 e = entry_at(sp);
+        node = (int32_t)e.x;
+        t_near = __uint_as_float(e.y);
+        t_far = sp == sb ? t_exit : __uint_as_float(entry_at(sp - 1).y);
+    };
+
+    while (__ballot(walking)) {
+        {
+            // hand the bottom stack entry - the farthest, largest pending subtree - of lanes still
+            // walking to lanes that have their answer
+            const unsigned long long idle_m = ~__ballot(walking);
+            const bool can_give = walking && sp > sb;
+            const unsigned long long donor_m = __ballot(can_give);
+            const int n_pairs = min((int)__popcll(idle_m), (int)__popcll(donor_m));
+            if (n_pairs >= RT_STEAL_MIN_PAIRS) {
+                const int rank_idle = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                const int rank_donor = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(donor_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donor_m, 0u));
+                const bool gives = can_give && rank_donor < n_pairs;
+                const bool takes = !walking && rank_idle < n_pairs;
+                if (gives) stk.slot[rank_donor] = lane;
+                __syncthreads();                    // one wave per workgroup: orders the LDS write and read
+                int src = lane;
+                if (takes) src = stk.slot[rank_idle];
+                __syncthreads();
+                u32x2 g = {0u, 0u};
+                float g_exit = 0;
+                if (gives) {
+                    g = entry_at(sb);
+                    g_exit = t_exit;
+                    t_exit = __uint_as_float(g.y);  // what remains with the giver ends where the given part begins
+                    sb++;
+                }
+                const V3 no = v3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
+                const V3 nd = v3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
+                const int n_owner = __shfl(owner, src);
+                const int32_t n_node = __shfl((int)g.x, src);
+                const float n_t = __uint_as_float((unsigned)__shfl((int)g.y, src)), n_exit = __shfl(g_exit, src);
+                if (takes) {
+                    r.o = no; r.d = nd; owner = n_owner;
+                    ox = (float)no.x; oy = (float)no.y; oz = (float)no.z;
+                    ix = reciprocal(nd.x); iy = reciprocal(nd.y); iz = reciprocal(nd.z);
+                    node = n_node; t_near = n_t; t_far = n_exit; t_exit = n_exit;
+                    sp = 0; sb = 0;
+                    found = false; walking = true;
+                }
+            }
+        }
+#ifdef RT_PHASE_TIMERS
+        {
+            const unsigned long long n_walking = __popcll(__ballot(walking));
+            if (lane == 0) { atomicAdd(&g_phase_cycles[28], 1ull); atomicAdd(&g_phase_cycles[29], n_walking); }
+        }
+#endif
+        int32_t first = 0, count = 0;
+        bool parked = false;
+        int skips = 0, loads = 0;
+        if (walking) {
+            auto step = [&](const rtamd_kdnode& nd) {
+                w.node();
+                const int ax = nd.b;
+                const float split = (float)nd.split;
+                const float o = axis_of_f(ox, oy, oz, ax);
+                const float inv = axis_of_f(ix, iy, iz, ax);
+                const float t = (split - o) * inv;
+                int32_t near_n, far_n;
+                if (split >= o) { near_n = node + 1; far_n = nd.a; }
+                else            { near_n = nd.a;     far_n = node + 1; }
+                if (t >= t_far || t < 0) {
+                    node = near_n;
+                } else if (t <= t_near) {
+                    node = far_n;
+                } else {
+                    const u32x2 e = {(unsigned)far_n, __float_as_uint(t)};
+                    if (sp < LDS_STACK) lds[sp * 64 + lane] = e;
+                    else deep[sp - LDS_STACK] = e;
+                    sp++;
+                    node = near_n;
+                    t_far = t;
+                }
+            };
+            for (;;) {
+                const rtamd_kdnode* rec = S.kd_triples + (int64_t)node * 4;
+                rtamd_kdnode nd = rec[0], left = rec[1], right = rec[2];
+                w.x_record();
+                while ((nd.b & 3) != 3) {
+                    const int32_t left_index = node + 1;
+                    step(nd);
+                    nd = node == left_index ? left : right;
+                    if ((nd.b & 3) == 3) break;
+                    step(nd);
+                    if (++loads >= RT_MAX_LOADS) { parked = true; break; }
+                    rec = S.kd_triples + (int64_t)node * 4;
+                    nd = rec[0]; left = rec[1]; right = rec[2];
+                    w.x_record();
+                }
+                if (parked) break;
+                w.leaf();
+                first = nd.a;
+                count = nd.b >> 2;
+                bool touched = false;
+                if (count != 0) {
+                    w.x_box(32);
+                    const f4* box = reinterpret_cast<const f4*>(S.leaf_aabb + (int64_t)node * 8);
+                    const f4 a = box[0], b = box[1];
+                    const float x0 = (a.x - ox) * ix, x1 = (a.w - ox) * ix;
+                    const float y0 = (a.y - oy) * iy, y1 = (b.x - oy) * iy;
+                    const float z0 = (a.z - oz) * iz, z1 = (b.y - oz) * iz;
+                    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                    touched = !(tn > tf) && !(tf < 0.0f);
+                }
+                if (touched) break;
+                w.x_skip();
+                if (sp == sb) { walking = false; first = 0; count = 0; break; }
+                pop();
+                if (++skips >= RT_MAX_SKIPS) { parked = true; break; }
+            }
+        }
+        clk.lap(PH_DESCENT);
+        const bool at_leaf = walking && !parked;
+        const unsigned long long p16 = __ballot(at_leaf && count <= 16);
+        const unsigned long long p32 = __ballot(at_leaf && count > 16 && count <= 32);
+        if (p16) packed_leaves<COUNT, true, 16>(S, false, p16, r, first, count, w, found, best);
+        clk.lap(PH_PACK16);
+        if (p32) packed_leaves<COUNT, true, 32>(S, false, p32, r, first, count, w, found, best);
+        clk.lap(PH_PACK32);
+        // a leaf the build could not bring below 33 rows: one ray at a time, 64 rows per step
+        unsigned long long big = __ballot(at_leaf && count > 32);
+        if (big) {
+            const TriTable geom = tri_table(S);
+            while (big) {
+                const int src = first_lane(big);
+                big &= big - 1;
+                Ray q;
+                q.o = v3(bcast_d(r.o.x, src), bcast_d(r.o.y, src), bcast_d(r.o.z, src));
+                q.d = v3(bcast_d(r.d.x, src), bcast_d(r.d.y, src), bcast_d(r.d.z, src));
+                const int32_t qfirst = bcast_i(first, src), qcount = bcast_i(count, src);
+                for (int32_t c = 0; c < qcount; c += 64) {
+                    const bool in = c + lane < qcount;
+                    double a, b, t = 0;
+                    w.x_rows(in ? 1u : 0u, 72);
+                    w.x_tests(in ? 1u : 0u);
+                    const bool hit = in && tri_solve_ref(geom, qfirst + c + lane, q, a, b, t);
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm) {
+                        const double ht = bcast_d(t, first_lane(hm));
+                        if (lane == src) { best.t = ht; found = true; }
+                        break;
+                    }
+                }
+            }
+            clk.lap(PH_BIG_PLAIN);
+        }
+        // a hit answers the ray's owner and ends every lane that walks a part of that ray
+        unsigned long long hits = __ballot(walking && found);
+        while (hits) {
+            const int h = first_lane(hits);
+            const int o = bcast_i(owner, h);
+            const double ht = bcast_d(best.t, h);
+            if (walking && owner == o) walking = false;
+            if (lane == o) { out_found = true; out_t = ht; }
+            hits &= __ballot(walking && found);
+        }
+        if (walking && !parked) {
+            if (sp == sb) walking = false;
+            else pop();
+        }
+        clk.lap(PH_POP);
+    }
+    found = out_found;
+    best.t = out_t;
+}
+
 // One kd-tree query per active lane, all 64 lanes inside.
 //
 // The query runs in rounds.  In a round each lane walks the tree front to back exactly as
@@ -572,8 +788,19 @@ __device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bo
     bool steal_ok = STEAL && walking && (t_exit * (1.0 + 1e-9) + 1e-9 < limit);
 #ifndef RT_NO_SHADOW_SUBTREES
     // Whether such a ray is occluded does not depend on which leaf lists the triangle it hits:
-    // it walks the tree's shadow tree (the same triangles in a kd-tree built for this walk)
-    if (STEAL && steal_ok && use_leaf_aabb && T.shadow_root > 0) node = T.shadow_root;
+    // it walks the tree's shadow tree (the same triangles in a kd-tree built for this walk);
+    // only rays with a limit inside the tree's box go on below, on the reference's tree
+    if (STEAL && S.leaf_aabb != nullptr && T.shadow_root > 0) {
+        if (__ballot(steal_ok)) {
+            bool f2 = false;
+            TriHit b2;
+            b2.t = 0;
+            shadow_tree_wave<COUNT>(S, T, steal_ok, r, t_near, t_exit, limit_in > T_INF, stk, w, f2, b2);
+            if (steal_ok) { out_found = f2; out_t = b2.t; walking = false; }
+        }
+        if (!__ballot(walking)) { found = out_found; best.t = out_t; return; }
+        steal_ok = false;
+    }
 #endif
     PhaseClock clk;
     clk.start(SHADOW ? (limit_in > T_INF ? 36 : 8) : 0);     // shadow queries without a limit (ambient occlusion) apart

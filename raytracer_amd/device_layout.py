@@ -58,6 +58,7 @@ def _morton_order(centroids):
     return numpy.argsort(code, kind="stable")
 
 
+SHADOW_TREE_SLACK = 1.0e-5        # see shadow_tree_wave in csrc/rt_device.h
 SHADOW_TREE_MIN_ROWS = 512      # trees with at least this many rows get a shadow tree of their own
 AUX_MIN_ROWS = CHUNK  # leaves of more rows than this get a shadow subtree
 AUX_LEAF = 16       # rows at which a shadow subtree stops splitting
@@ -238,11 +239,16 @@ def _device_arrays(flat):
         extra_nodes, extra_rows, extra_boxes = [], [], []
         next_node, next_row = [len(nodes)], [n_refs]
 
-        def attach(src_rows, room):
-            """Build a shadow subtree over the table rows src_rows; (root index, levels) or None."""
+        def attach(src_rows, room, slack=0.0):
+            """Build a shadow subtree over the table rows src_rows; (root index, levels) or None.
+            `slack`: widen every triangle's box by this fraction of the largest coordinate, for a
+            walk in single precision (it lists a triangle wherever rounding could take the walk)."""
             g = geom[:, src_rows]
             v0, v1, v2 = g[0:3].T, (g[0:3] + g[3:6]).T, (g[0:3] + g[6:9]).T
             blo, bhi = _padded(numpy.minimum(numpy.minimum(v0, v1), v2), numpy.maximum(numpy.maximum(v0, v1), v2))
+            if slack:
+                wide = slack * max(float(numpy.abs(blo).max()), float(numpy.abs(bhi).max()), 1e-30)
+                blo, bhi = blo - wide, bhi + wide
             built = _shadow_subtree(blo, bhi, room)
             if built is None:
                 return None
@@ -276,7 +282,7 @@ def _device_arrays(flat):
             firsts = numpy.sort(firsts[(ids[firsts] & (1 << 30)) == 0])
             if not len(firsts):
                 continue
-            got = attach(lo_r + firsts, capi.MAX_TREE_DEPTH)
+            got = attach(lo_r + firsts, capi.MAX_TREE_DEPTH, SHADOW_TREE_SLACK)
             if got is not None:
                 t.shadow_root = got[0]
                 t.depth = max(t.depth, got[1])

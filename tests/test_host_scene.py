@@ -208,7 +208,8 @@ def check_shadow_subtrees(dev, nodes, n_nodes, geom, n_rows, whole_trees):
                 assert t.shadow_root >= n_nodes
                 ids = prim[t.ref_offset:end]
                 _, firsts = numpy.unique(ids, return_index=True)
-                jobs.append((t.shadow_root, t.ref_offset + numpy.sort(firsts[(ids[firsts] >> 30) == 0]), capi.MAX_TREE_DEPTH))
+                jobs.append((t.shadow_root, t.ref_offset + numpy.sort(firsts[(ids[firsts] >> 30) == 0]), capi.MAX_TREE_DEPTH,
+                             device_layout.SHADOW_TREE_SLACK))
             else:
                 assert t.shadow_root == 0
         assert jobs
@@ -217,11 +218,15 @@ def check_shadow_subtrees(dev, nodes, n_nodes, geom, n_rows, whole_trees):
         assert len(big) and set(numpy.nonzero(roots)[0]) == set(big) and all(t.shadow_root == 0 for t in trees)
         for leaf in big:
             first, count = int(nodes["a"][leaf]), int(nodes["b"][leaf]) >> 2
-            jobs.append((int(roots[leaf]), numpy.arange(first, first + count), device_layout.AUX_DEPTH))
-    for root, src, max_levels in jobs:
+            jobs.append((int(roots[leaf]), numpy.arange(first, first + count), device_layout.AUX_DEPTH, 0.0))
+    for root, src, max_levels, slack in jobs:
         g = geom[:, src]
         v = numpy.stack([g[0:3], g[0:3] + g[3:6], g[0:3] + g[6:9]])
         lo, hi = device_layout._padded(v.min(axis=0).T, v.max(axis=0).T)
+        # a tree walked in single precision lists every triangle a little beyond its box
+        wide = slack * max(numpy.abs(lo).max(), numpy.abs(hi).max())
+        assert slack == 0.0 or wide > 1e-6 * numpy.abs(v).max()
+        lo, hi = lo - wide, hi + wide
         todo = [(root, lo.min(axis=0), hi.max(axis=0), 0, numpy.arange(len(src)))]
         seen = numpy.zeros(len(src), dtype=bool)
         while todo:
