@@ -323,6 +323,13 @@ struct KdStack {
 #ifndef RT_STEAL_MIN_PAIRS
 #define RT_STEAL_MIN_PAIRS 1      // hand walks over only when at least this many lanes can take one (1: 17.72, 4: 17.81, 12: 18.36, never: 18.19 ms)
 #endif
+// the same two limits for the single-precision walk of shadow trees
+#ifndef RT_ST_MAX_SKIPS
+#define RT_ST_MAX_SKIPS 1
+#endif
+#ifndef RT_ST_MAX_LOADS
+#define RT_ST_MAX_LOADS 3
+#endif
 constexpr int SMALL_LEAF = RT_SMALL_LEAF;     // leaves up to this size are scanned by the lane that reached them
 
 // BoundingBox.hit (geometry.py:49-70) on the tree's root box.
@@ -526,10 +533,16 @@ __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& 
 // work as in kd_query_wave below.  A stack entry is (node, t at the plane as a float) in eight
 // bytes, the first LDS_STACK of every lane in the LDS array the double-precision walk keeps its
 // t values in.
-template <int COUNT>
-__device__ void shadow_tree_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool walking, const Ray& ray_in,
+//
+// A lane may bring a second ray (TWO): it starts on it as soon as its part of the first ray's
+// walk is done, which keeps more lanes walking per round than two queries in a row would.
+// Rays are told apart by `owner` = lane + 64 * (second ray).
+template <int COUNT, bool TWO = false>
+__device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool walking, const Ray& ray_in,
                                  double near_in, double exit_in, bool unlimited, const KdStack& stk,
-                                 Work<COUNT>& w, bool& found, TriHit& best) {
+                                 Work<COUNT>& w, bool& found, TriHit& best,
+                                 bool pending2 = false, const Ray* ray2 = nullptr, double near2 = 0, double exit2 = 0,
+                                 bool* found2 = nullptr) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     const int lane = lane_id();
     Ray r = ray_in;                         // own ray, or the one whose walk this lane took over
@@ -541,7 +554,7 @@ __device__ void shadow_tree_wave(const rtamd_scene_desc& S, const rtamd_tree& T,
     u32x2 deep[STACK_MAX - LDS_STACK];
     int sp = 0, sb = 0, owner = lane;
     int32_t node = T.shadow_root;
-    bool out_found = false;
+    bool out_found = false, out_found2 = false;
     double out_t = 0;
     found = false;
     PhaseClock clk;
@@ -557,7 +570,18 @@ __device__ void shadow_tree_wave(const rtamd_scene_desc& S, const rtamd_tree& T,
         t_far = sp == sb ? t_exit : __uint_as_float(entry_at(sp - 1).y);
     };
 
-    while (__ballot(walking)) {
+    while (__ballot(walking || (TWO && pending2))) {
+        if (TWO && pending2 && !walking) {
+            // this lane's part of its first ray's walk is done: on to its second ray
+            pending2 = false;
+            r = *ray2;
+            ox = (float)r.o.x; oy = (float)r.o.y; oz = (float)r.o.z;
+            ix = reciprocal(r.d.x); iy = reciprocal(r.d.y); iz = reciprocal(r.d.z);
+            node = T.shadow_root;
+            t_near = (float)near2; t_far = t_exit = (float)exit2;
+            sp = 0; sb = 0; owner = lane + 64;
+            found = false; walking = true;
+        }
         {
             // hand the bottom stack entry - the farthest, largest pending subtree - of lanes still
             // walking to lanes that have their answer
@@ -641,7 +665,7 @@ __device__ void shadow_tree_wave(const rtamd_scene_desc& S, const rtamd_tree& T,
                     nd = node == left_index ? left : right;
                     if ((nd.b & 3) == 3) break;
                     step(nd);
-                    if (++loads >= RT_MAX_LOADS) { parked = true; break; }
+                    if (++loads >= RT_ST_MAX_LOADS) { parked = true; break; }
                     rec = S.kd_triples + (int64_t)node * 4;
                     nd = rec[0]; left = rec[1]; right = rec[2];
                     w.x_record();
@@ -666,7 +690,7 @@ __device__ void shadow_tree_wave(const rtamd_scene_desc& S, const rtamd_tree& T,
                 w.x_skip();
                 if (sp == sb) { walking = false; first = 0; count = 0; break; }
                 pop();
-                if (++skips >= RT_MAX_SKIPS) { parked = true; break; }
+                if (++skips >= RT_ST_MAX_SKIPS) { parked = true; break; }
             }
         }
         clk.lap(PH_DESCENT);
@@ -711,7 +735,10 @@ __device__ void shadow_tree_wave(const rtamd_scene_desc& S, const rtamd_tree& T,
             const int o = bcast_i(owner, h);
             const double ht = bcast_d(best.t, h);
             if (walking && owner == o) walking = false;
-            if (lane == o) { out_found = true; out_t = ht; }
+            if (lane == (o & 63)) {
+                if (TWO && o >= 64) out_found2 = true;
+                else { out_found = true; out_t = ht; }
+            }
             hits &= __ballot(walking && found);
         }
         if (walking && !parked) {
@@ -722,6 +749,7 @@ __device__ void shadow_tree_wave(const rtamd_scene_desc& S, const rtamd_tree& T,
     }
     found = out_found;
     best.t = out_t;
+    if (TWO) *found2 = out_found2;
 }
 
 // One kd-tree query per active lane, all 64 lanes inside.
@@ -742,7 +770,7 @@ __device__ void shadow_tree_wave(const rtamd_scene_desc& S, const rtamd_tree& T,
 // with a hit.  SHADOW = true is KDTree.shadow_hit (kdtree.py:157-164): the first item in
 // leaf order that reports a hit ends the query and its t is returned.
 template <int COUNT, bool SHADOW>
-__device__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool active, const Ray& ray_in,
+__device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const rtamd_tree& T, bool active, const Ray& ray_in,
                               double limit_in, bool coherent, const KdStack& stk, Work<COUNT>& w, bool& found,
                               TriHit& best) {
     found = false;
@@ -1452,7 +1480,7 @@ struct Hit {
 
 // World.hit_objects (main.py:35-46) for every active lane: objects in list order, strict `<`.
 template <int COUNT, bool TREES>
-__device__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, bool active, bool coherent, const Ray& ray,
+__device__ __forceinline__ bool closest_hit_wave(const rtamd_scene_desc& S, const KdStack& stk, bool active, bool coherent, const Ray& ray,
                                  Work<COUNT>& w, Hit& h) {
     if (active) w.closest++;
     double tmin = T_INF;
@@ -1560,7 +1588,7 @@ __device__ __forceinline__ bool analytic_shadow(const rtamd_object& ob, const Ra
 }
 
 template <int COUNT, bool TREES, bool ONE_TREE = false>
-__device__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, bool need, const Ray& ray,
+__device__ __forceinline__ bool occluded_wave(const rtamd_scene_desc& S, const KdStack& stk, bool need, const Ray& ray,
                               bool use_limit, double limit, Work<COUNT>& w) {
     if (need) w.shadow++;
     bool occ = false;
@@ -1692,8 +1720,125 @@ __device__ __forceinline__ V3 texture_color(const rtamd_scene_desc& S, int tex, 
 // EXT: `tex` is the texture colour of an SV_Matte hit (material.py:311-326), which scales
 // ka and kd and adds the viewer-side test of :319.
 template <int COUNT, bool EXT, bool TREES, bool ONE_TREE = false>
-__device__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, bool lit, const rtamd_material& m,
+__device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, bool lit, const rtamd_material& m,
                                 const Hit& h, V3 wo, bool area, V3 tex, Draw& dr, Work<COUNT>& w) {
+#ifndef RT_NO_FUSED_SHADOWS
+    if (ONE_TREE && COUNT != 1 && !EXT && S.ambient.kind == RTAMD_AMBIENT_OCCLUDER && S.lights[0].cast_shadow &&
+        S.leaf_aabb != nullptr) {
+        // One kd-tree, an ambient occluder and one shadow-casting light: the occlusion ray and
+        // the light's shadow ray of a hit are both known before either is traced (no draw
+        // happens inside a query), and which is traced first changes neither answer.  When the
+        // tree has a shadow tree and any hit decides both, the wave traces them in one query.
+        int tree_object = 0;
+        for (int i = 0; i < S.n_objects; ++i) if (S.objects[i].kind == RTAMD_KDTREE) tree_object = i;
+        const rtamd_object& tob = S.objects[tree_object];
+        const rtamd_tree& T = S.trees[tob.tree];
+        if (T.shadow_root > 0) {
+            const rtamd_light& lt = S.lights[0];
+            const Draw drawn = dr;          // if the wave cannot take this path the draws are made again below
+            // ambient_color.L(sr), AmbientOccluder (light.py:85-100)
+            Ray r1;
+            r1.o = h.p;
+            r1.d = v3(0, 0, 1);
+            if (lit) r1.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
+            // the light's direction, term and shadow ray, as in the loop below
+            V3 wi = v3(0, 0, 1), sample_point = v3(0, 0, 0);
+            if (lit) {
+                switch (lt.kind) {
+                case RTAMD_POINT: { const V3 v = ld3(lt.position) - h.p; wi = v / norm(v); } break;
+                case RTAMD_DIRECTIONAL: wi = ld3(lt.position); break;
+                case RTAMD_AREA: {
+                    double sx, sy;
+                    draw_square(S, lt.sampler, dr, sx, sy);
+                    sample_point = (ld3(lt.position) + sx * ld3(lt.edge_u)) + sy * ld3(lt.edge_v);
+                    const V3 v = sample_point - h.p;
+                    wi = v / norm(v);
+                } break;
+                default: wi = hemisphere_about(h.n, draw_hemisphere(S, lt.sampler, dr)); break;
+                }
+            }
+            const double ndotwi = dot(h.n, wi);
+            const bool facing = lit && ndotwi > 0;
+            const bool phong = m.kind != RTAMD_MATTE;
+            const bool gate = (phong || area) ? (m.receives_shadow != 0) : true;
+            const bool wanted = facing && gate;
+            V3 term = v3(0, 0, 0);
+            if (wanted) {
+                V3 f = ld3(m.diffuse);
+                if (phong) f = f + phong_lobe<!TREES>(ld3(m.specular), m.exp, h.n, wo, wi);
+                V3 Ll = ld3(lt.radiance);
+                if (lt.kind == RTAMD_POINT && lt.attenuation != 0)
+                    Ll = Ll * rt_pow<!TREES>(norm(h.p - ld3(lt.position)) / lt.radius, -lt.attenuation);
+                if (lt.kind == RTAMD_AREA && !(dot(ld3(lt.normal), wi) < 0.)) Ll = v3(0, 0, 0);
+                term = (f * Ll) * ndotwi;
+                if (area) {
+                    double G = 1.0, pdf = 1.0;
+                    if (lt.kind == RTAMD_AREA) {
+                        const double ndotd = -dot(ld3(lt.normal), wi);
+                        const V3 dv = sample_point - h.p;
+                        const double d2 = (((0 + dv.x * dv.x) + dv.y * dv.y) + dv.z * dv.z) / (lt.radius * lt.radius);
+                        G = ndotd / pymax(1., d2);
+                        pdf = lt.pdf;
+                    }
+                    term = (term * G) / pdf;
+                }
+            }
+            Ray r2;
+            r2.o = h.p;
+            r2.d = wi;
+            double limit = 0;
+            if (lt.kind == RTAMD_POINT) limit = norm(r2.o - ld3(lt.position));
+            else if (lt.kind == RTAMD_AREA) limit = dot(sample_point - r2.o, r2.d);
+            const bool bounded = lt.kind == RTAMD_POINT || lt.kind == RTAMD_AREA;
+            // any hit decides a ray of the light whose limit lies beyond the tree's box (always, for
+            // the occlusion ray); a wave with a light ray that ends inside the box takes the
+            // general path below
+            const Ray q1 = tob.has_transform ? to_object_space(S, tob, r1) : r1;
+            const Ray q2 = tob.has_transform ? to_object_space(S, tob, r2) : r2;
+            double near1 = 0, exit1 = 0, near2 = 0, exit2 = 0;
+            const bool casts = T.shadow_casters != RTAMD_CASTERS_NONE;
+            const bool in1 = casts && lit && root_box(T, q1, near1, exit1);
+            const bool in2 = casts && facing && root_box(T, q2, near2, exit2);
+            const bool free2 = !bounded || (exit2 * (1.0 + 1e-9) + 1e-9 < limit);
+            if (!__ballot(in2 && !free2)) {
+                w.mark(34);
+                // light.in_shadow for both rays: the analytic objects first, the tree last
+                if (lit) w.shadow++;
+                if (facing) w.shadow++;
+                bool occ1 = false, occ2 = false;
+                for (int i = 0; i < S.n_objects; ++i) {
+                    const rtamd_object& ob = S.objects[i];
+                    if (ob.kind == RTAMD_KDTREE || !ob.cast_shadow) continue;
+                    double t = 0;
+                    if (lit && !occ1) {
+                        const Ray r = ob.has_transform ? to_object_space(S, ob, r1) : r1;
+                        w.analytic();
+                        if (analytic_shadow(ob, r, t)) occ1 = true;
+                    }
+                    if (facing && !occ2) {
+                        const Ray r = ob.has_transform ? to_object_space(S, ob, r2) : r2;
+                        w.analytic();
+                        if (analytic_shadow(ob, r, t) && (!bounded || t < limit)) occ2 = true;
+                    }
+                }
+                const bool walk1 = in1 && !occ1, walk2 = in2 && !occ2;
+                bool f1 = false, f2 = false;
+                TriHit th;
+                th.t = 0;
+                if (__ballot(walk1 || walk2))
+                    shadow_tree_wave<COUNT, true>(S, T, walk1, q1, near1, exit1, true, stk, w, f1, th, walk2, &q2, near2, exit2, &f2);
+                occ1 = occ1 || (walk1 && f1);
+                occ2 = occ2 || (walk2 && f2);
+                w.mark(18);
+                const V3 amb = occ1 ? ld3(S.ambient.occluded) : ld3(S.ambient.radiance);
+                V3 L = ld3(m.ambient) * amb;
+                if (wanted && !occ2) L = L + term;
+                return L;
+            }
+            dr = drawn;
+        }
+    }
+#endif
     // ambient_color.L(sr): AmbientLight (light.py:14-15) or AmbientOccluder (light.py:85-100)
     V3 amb = ld3(S.ambient.radiance);
     if (S.ambient.kind == RTAMD_AMBIENT_OCCLUDER) {
@@ -1830,7 +1975,7 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(rt_pow<false>(b.x
 // shadow queries.  The instantiation is launched for scenes with exactly one kd-tree object,
 // which the shadow tests then ask last (occluded_wave<..., ONE_TREE>), and exactly one light.
 template <int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
-__device__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
+__device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, Primary& first) {
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
     const int tracer_kind = AREA_ONLY ? (int)RTAMD_TRACER_AREA : S.tracer_kind;
