@@ -582,6 +582,35 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
             sp = 0; sb = 0; owner = lane + 64;
             found = false; walking = true;
         }
+        if (TWO) {
+            // second rays that wait behind a first ray still being walked go to lanes with nothing to do
+            const unsigned long long idle_m = ~__ballot(walking);
+            const unsigned long long donor_m = __ballot(walking && pending2);
+            const int n_pairs = min((int)__popcll(idle_m), (int)__popcll(donor_m));
+            if (n_pairs > 0) {
+                const int rank_idle = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                const int rank_donor = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(donor_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donor_m, 0u));
+                const bool gives = walking && pending2 && rank_donor < n_pairs;
+                const bool takes = !walking && rank_idle < n_pairs;
+                if (gives) stk.slot[rank_donor] = lane;
+                __syncthreads();                    // one wave per workgroup: orders the LDS write and read
+                int src = lane;
+                if (takes) src = stk.slot[rank_idle];
+                __syncthreads();
+                const V3 no = v3(__shfl(ray2->o.x, src), __shfl(ray2->o.y, src), __shfl(ray2->o.z, src));
+                const V3 nd = v3(__shfl(ray2->d.x, src), __shfl(ray2->d.y, src), __shfl(ray2->d.z, src));
+                const float n_near = __shfl((float)near2, src), n_exit = __shfl((float)exit2, src);
+                if (gives) pending2 = false;
+                if (takes) {
+                    r.o = no; r.d = nd; owner = src + 64;
+                    ox = (float)no.x; oy = (float)no.y; oz = (float)no.z;
+                    ix = reciprocal(nd.x); iy = reciprocal(nd.y); iz = reciprocal(nd.z);
+                    node = T.shadow_root; t_near = n_near; t_far = n_exit; t_exit = n_exit;
+                    sp = 0; sb = 0;
+                    found = false; walking = true;
+                }
+            }
+        }
         {
             // hand the bottom stack entry - the farthest, largest pending subtree - of lanes still
             // walking to lanes that have their answer
