@@ -241,10 +241,11 @@ typedef struct rtamd_texture {
  *                       may be NULL with n_chunks = 0
  *   leaf_boxes[n_chunks][9][6] = the same chunk box followed by the boxes of the chunk's eight
  *                       8-row cells (unused cells zero), and
- *   tri_rows[n_refs][10] = row-major copy of tri_geom with {tri_prim, tri_order} packed into
+ *   tri_rows[..][10]  = row-major copy of tri_geom with {tri_prim, tri_order} packed into
  *                       the tenth double: what a single lane reads when it scans a boxed
  *                       leaf for its own ray.  Both optional (NULL: the wave scans such
- *                       leaves together, chunk by chunk).
+ *                       leaves together, chunk by chunk).  It needs rows for the leaves of
+ *                       the trees proper only, not for those of shadow trees (rtamd_tree).
  * Per-primitive tables (one row per triangle, all trees concatenated):
  *   prim_normals      = unit face normal [3], or n0,n1,n2 [9] for smooth trees; rows
  *                       are addressed through prim_normal_offset[prim] (in doubles)
@@ -279,7 +280,7 @@ typedef struct rtamd_scene_desc {
     const double *tri_geom;             /* device */
     const int32_t *tri_prim;            /* device */
     const int32_t *tri_order;           /* device, optional */
-    const double *tri_rows;             /* device, optional: [n_refs][10] row-major copy of tri_geom,
+    const double *tri_rows;             /* device, optional: [rows of the trees proper][10] row-major copy of tri_geom,
                                            tenth double = {tri_prim, tri_order} as two int32 */
     const double *leaf_boxes;           /* device, optional: [n_chunks][9][6] = per chunk its own
                                            box (as chunk_boxes) and the boxes of its eight

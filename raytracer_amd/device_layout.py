@@ -310,11 +310,7 @@ def _device_arrays(flat):
             a["tri_geom"] = numpy.ascontiguousarray(geom).ravel()
             a["tri_prim"] = prim
             a["tri_order"] = order
-            rows = numpy.zeros((len(prim), 10))
-            rows[:, :9] = geom.T
-            rows[:, 9] = numpy.stack([prim.astype(numpy.int32), order], axis=1).copy().view(numpy.float64)[:, 0]
-            a["tri_rows"] = rows.ravel()
-            a["trees"] = trees
+            a["trees"] = trees          # (`tri_rows` stays as it is: only scans by single lanes read it, never in these trees)
     a["leaf_aabb"] = la32.ravel()
     a["kd_nodes"] = nodes.view(numpy.uint8)
     # node, left child, right child side by side: two levels of the walk per load
