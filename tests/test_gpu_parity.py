@@ -592,3 +592,45 @@ def test_executed_work_counters_on_the_dragon(torch_gpu):
     with pytest.raises(RuntimeError):
         fb = runtime.FrameBuffers(ds, tiles)
         ds.render_tiles(cam, world.seed, fb.tile_ids, 0, 16, sum_rgb8=fb.sum_rgb8, count_executed=True, count_work=True)
+
+
+@pytest.mark.parametrize("case", ("panel_inside_the_box", "phong_dragon", "teapot_smooth"))
+def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
+    """One kd-tree, an ambient occluder, one light, AreaLightTracer: the whole-frame kernel traces
+    both shadow rays of a hit in one query on the mesh's shadow tree - unless some light ray
+    ends inside the mesh's box, which sends the wave down the general path.  Both ways, a glossy
+    material and a smooth mesh: timed = executed-work = reference-work kernel = oracle."""
+    import numpy as np
+    import raytracer_amd
+    raytracer_amd.activate()
+    from geometry import Rectangle
+    from light import AmbientOccluder, AreaLight
+    from material import Emissive, Phong
+    from raytracer_amd import flatten
+    if case == "teapot_smooth":
+        from raytracer_amd.world import World
+        from tracer import AreaLightTracer
+        world = World(viewmode="parallel", buildfunction="k", seed=3)
+        sampler = world.viewplane.sampler
+        world.tracer = AreaLightTracer(world)
+        world.ambient_color = AmbientOccluder(np.array((1., 1., 1.)), .4, sampler)
+        panel = Rectangle(np.array((-2., 6., 7.)), 4, 3, np.array((0., 0., -1.)), np.array((1., 0., 0.)),
+                          Emissive(20., np.array((1., .95, .9))), sampler)
+        world.lights = [AreaLight(panel.material, panel, 5.)]
+        tiles, samples = 200, None
+    else:
+        world = _tiny_world("dragon_area", resolution=(256, 144), sample_dim=2, seed=5)
+        sampler = world.viewplane.sampler
+        if case == "panel_inside_the_box":
+            # the emitter hangs between the dragon's coils: light rays end inside the tree's box
+            panel = Rectangle(np.array((-3., 4., 1.)), 3, 2, np.array((0., 0., -1.)), np.array((1., 0., 0.)),
+                              Emissive(30., np.array((1., .96, .9))), sampler)
+            world.lights = [AreaLight(panel.material, panel, 6.)]
+        else:
+            tree = world.objects[0]
+            shiny = Phong(ka=.6, kd=.7, ks=.5, exp=30, cd=np.array((1., .84, .1)))
+            for box in tree.boxes:
+                box.obj.material = shiny
+        tiles, samples = 120, None
+    world.invalidate()
+    check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), tiles, samples, case)
