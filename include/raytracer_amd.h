@@ -207,7 +207,11 @@ typedef struct rtamd_tree {
                                of the root of another kd-tree over the same triangles, any
                                shape, with leaf_aabb rows for its leaves: shadow queries that
                                any hit decides (no limit, or the ray leaves bbox before its
-                               limit) walk this tree instead; needs leaf_aabb      */
+                               limit) walk this tree instead, in single precision: a
+                               triangle must be listed in every leaf whose cell its box,
+                               widened by 4e-5 of the largest coordinate of bbox, reaches
+                               into, and the leaves' leaf_aabb rows must be widened
+                               alike; needs leaf_aabb                               */
     int32_t reserved;
 } rtamd_tree;
 enum { RTAMD_CASTERS_ALL = 0, RTAMD_CASTERS_NONE = 1, RTAMD_CASTERS_MIXED = 2 };

@@ -516,6 +516,15 @@ __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& 
     }
 }
 
+// The single-precision walk of a shadow tree (below) is only as exact as the ray's origin is in
+// single precision: an origin whose coordinates are much larger than the tree's own would move
+// the walk by more than the slack the tree was built with.  Such rays take the exact walk.
+__device__ __forceinline__ bool origin_near_tree(const rtamd_tree& T, V3 o) {
+    const double reach = fmax(fmax(fmax(fabs(T.bbox_lo[0]), fabs(T.bbox_hi[0])), fmax(fabs(T.bbox_lo[1]), fabs(T.bbox_hi[1]))),
+                              fmax(fabs(T.bbox_lo[2]), fabs(T.bbox_hi[2])));
+    return fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)) <= 16.0 * reach;
+}
+
 // Shadow queries that any hit decides, on a tree's shadow tree (rtamd_tree::shadow_root).
 //
 // Such a query asks only whether some triangle is hit anywhere on the ray inside the tree's box:
@@ -525,8 +534,9 @@ __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& 
 // reciprocal direction, plane distances, interval bounds and leaf boxes), which halves the
 // registers and the instructions of a step.  What makes that safe is in the tree, not here: the
 // host lists a triangle in every leaf whose cell its box reaches into after widening the box
-// by far more (1e-5 of the scene's extent) than the walk's rounding can move a point
-// (about 1e-6 of it), and widens the leaf boxes by the same amount.  The triangle tests are
+// by far more (4e-5 of the tree's largest coordinate) than the walk's rounding can move a point
+// (about 4e-6 of it for an origin within 16 times that coordinate, see origin_near_tree), and
+// widens the leaf boxes by the same amount.  The triangle tests are
 // the exact double-precision ones.
 //
 // Rounds, short rounds, hand-over of the bottom stack entry to idle lanes and packed leaf steps
@@ -848,12 +858,13 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
     // it walks the tree's shadow tree (the same triangles in a kd-tree built for this walk);
     // only rays with a limit inside the tree's box go on below, on the reference's tree
     if (STEAL && S.leaf_aabb != nullptr && T.shadow_root > 0) {
-        if (__ballot(steal_ok)) {
+        const bool fast = steal_ok && origin_near_tree(T, r.o);
+        if (__ballot(fast)) {
             bool f2 = false;
             TriHit b2;
             b2.t = 0;
-            shadow_tree_wave<COUNT>(S, T, steal_ok, r, t_near, t_exit, limit_in > T_INF, stk, w, f2, b2);
-            if (steal_ok) { out_found = f2; out_t = b2.t; walking = false; }
+            shadow_tree_wave<COUNT>(S, T, fast, r, t_near, t_exit, limit_in > T_INF, stk, w, f2, b2);
+            if (fast) { out_found = f2; out_t = b2.t; walking = false; }
         }
         if (!__ballot(walking)) { found = out_found; best.t = out_t; return; }
         steal_ok = false;
@@ -1829,7 +1840,8 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
             const bool in1 = casts && lit && root_box(T, q1, near1, exit1);
             const bool in2 = casts && facing && root_box(T, q2, near2, exit2);
             const bool free2 = !bounded || (exit2 * (1.0 + 1e-9) + 1e-9 < limit);
-            if (!__ballot(in2 && !free2)) {
+            const bool near = origin_near_tree(T, q1.o);          // both rays start at the hit point
+            if (!__ballot((in2 && !free2) || ((in1 || in2) && !near))) {
                 w.mark(34);
                 // light.in_shadow for both rays: the analytic objects first, the tree last
                 if (lit) w.shadow++;

@@ -58,7 +58,7 @@ def _morton_order(centroids):
     return numpy.argsort(code, kind="stable")
 
 
-SHADOW_TREE_SLACK = 1.0e-5        # see shadow_tree_wave in csrc/rt_device.h
+SHADOW_TREE_SLACK = 4.0e-5        # see shadow_tree_wave in csrc/rt_device.h
 SHADOW_TREE_MIN_ROWS = 512      # trees with at least this many rows get a shadow tree of their own
 AUX_MIN_ROWS = CHUNK  # leaves of more rows than this get a shadow subtree
 AUX_LEAF = 16       # rows at which a shadow subtree stops splitting

@@ -594,7 +594,7 @@ def test_executed_work_counters_on_the_dragon(torch_gpu):
         ds.render_tiles(cam, world.seed, fb.tile_ids, 0, 16, sum_rgb8=fb.sum_rgb8, count_executed=True, count_work=True)
 
 
-@pytest.mark.parametrize("case", ("panel_inside_the_box", "phong_dragon", "teapot_smooth"))
+@pytest.mark.parametrize("case", ("panel_inside_the_box", "phong_dragon", "teapot_smooth", "tiny_instance"))
 def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
     """One kd-tree, an ambient occluder, one light, AreaLightTracer: the whole-frame kernel traces
     both shadow rays of a hit in one query on the mesh's shadow tree - unless some light ray
@@ -607,7 +607,17 @@ def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
     from light import AmbientOccluder, AreaLight
     from material import Emissive, Phong
     from raytracer_amd import flatten
-    if case == "teapot_smooth":
+    if case == "tiny_instance":
+        # the teapot at a fiftieth of its size: in its own space the shadow rays of the ground
+        # start hundreds of teapots away, too far for the single-precision walk, which must
+        # leave them to the exact one
+        import affinetransform as transform
+        from geometry import Instance
+        from raytracer_amd.world import World
+        world = World(viewmode="parallel", buildfunction="k", seed=3)
+        world.objects[0] = Instance(world.objects[0], transform.translate(0.5, 0.0, 4.5).dot(transform.scale(0.02, 0.02, 0.02)))
+        tiles, samples = 625, None
+    elif case == "teapot_smooth":
         from raytracer_amd.world import World
         from tracer import AreaLightTracer
         world = World(viewmode="parallel", buildfunction="k", seed=3)
