@@ -211,7 +211,7 @@ typedef struct rtamd_tree {
                                triangle must be listed in every leaf whose cell its box,
                                widened by 4e-5 of the largest coordinate of bbox, reaches
                                into, and the leaves' leaf_aabb rows must be widened
-                               alike; needs leaf_aabb                               */
+                               alike; ignored without leaf_aabb                     */
     int32_t reserved;
 } rtamd_tree;
 enum { RTAMD_CASTERS_ALL = 0, RTAMD_CASTERS_NONE = 1, RTAMD_CASTERS_MIXED = 2 };

@@ -569,6 +569,7 @@ static int scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
         const rtamd_tree& t = trees[i];
         if (t.depth + 2 > STACK_MAX) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "kd-tree deeper than the traversal stack%s"); }
         if (t.node_offset < 0 || t.node_offset >= d->n_kd_nodes) { rtamd_scene_destroy(s); return fail(RTAMD_EINVAL, "tree root outside kd_nodes%s"); }
+        if (t.shadow_root < 0 || t.shadow_root >= d->n_kd_nodes) { rtamd_scene_destroy(s); return fail(RTAMD_EINVAL, "shadow tree root outside kd_nodes%s"); }
         if (t.depth > s->max_tree_depth) s->max_tree_depth = t.depth;
     }
     *out = s;

@@ -139,6 +139,23 @@ def test_empty_and_error_paths(torch_gpu):
     bad = capi.Camera()
     assert lib.rtamd_render_pixels(ds.handle, C.byref(bad), 1, 1, None, None, None, None, None, None, 0, None) != 0
     assert b"view plane" in lib.rtamd_last_error()
+    # a tree whose shadow tree lies outside the node table is refused
+    world = common.world_for("features_mesh")
+    ds = runtime.device_scene(world)
+    trees = (capi.Tree * (ds.tensors["trees"].numel() // C.sizeof(capi.Tree))).from_buffer_copy(ds.tensors["trees"].cpu().numpy().tobytes())
+    assert trees[0].shadow_root > 0
+    for break_it, message in ((lambda d, t: setattr(t[0], "shadow_root", d.n_kd_nodes + 7), b"shadow tree root"),
+                              (lambda d, t: setattr(t[0], "shadow_root", -3), b"shadow tree root")):
+        desc = ds.table_sizes(ds.flat.desc(lambda name, arr: ds.tensors[name].data_ptr()))
+        desc.kd_triples, desc.leaf_aabb = ds.tensors["kd_triples"].data_ptr(), ds.tensors["leaf_aabb"].data_ptr()
+        copy = (capi.Tree * len(trees)).from_buffer_copy(bytes(trees))
+        break_it(desc, copy)
+        import torch
+        dev_trees = torch.frombuffer(bytearray(bytes(copy)), dtype=torch.uint8).to(ds.device)
+        desc.trees = dev_trees.data_ptr()
+        handle = C.c_void_p()
+        assert lib.rtamd_scene_create(C.byref(desc), C.byref(handle)) != 0
+        assert message in lib.rtamd_last_error()
 
 
 def _tiny_world(scene, resolution=(8, 6), sample_dim=2, seed=1):
