@@ -67,6 +67,9 @@ PLAN = {
     "fuzz_0": ("parallel", None, 3000), "fuzz_1": ("parallel", None, 3000), "fuzz_2": ("parallel", None, 3000),
     "fuzz_3": ("parallel", None, 3000), "fuzz_4": ("parallel", None, 3000), "fuzz_5": ("parallel", None, 3000),
     "fuzz_6": ("parallel", None, 3000), "fuzz_7": ("parallel", None, 3000), "fuzz_8": ("parallel", None, 3000),
+    # the same with the teapot's kd-tree in them
+    "fuzzmesh_0": ("parallel", None, 2000), "fuzzmesh_1": ("parallel", None, 2000), "fuzzmesh_2": ("parallel", None, 2000),
+    "fuzzmesh_10": ("parallel", None, 2000),
     # RegularSampler everywhere (the scene files' "realtime" branch): no draws at all
     "glossyreflective@realtime": ("realtime", None, 3000),
     "mirrorhall@realtime": ("realtime", None, 2000),

@@ -187,3 +187,90 @@ def _make(k):
 
 
 WORLDS = [_make(k) for k in range(N_WORLDS)]
+
+
+# ---- `fuzzmesh_<k>`: the teapot (6 320 triangles, a tree big enough for a shadow tree) in random company
+N_MESH_WORLDS = 12
+
+
+def build_mesh_world(world, viewmode, k):
+    """The teapot's kd-tree (smooth or flat, bare or behind one or two Instances, some worlds with
+    triangles that cast no shadow) on a ground plane with a few analytic objects, lights inside
+    and outside the mesh's box, with and without limits: what decides which walk a shadow ray
+    takes on the device."""
+    r = numpy.random.RandomState(9000 + k)
+    kind = k % 3
+    world.viewmode = viewmode
+    dim = int(r.choice([1, 2]))
+    sampler = MultiJitteredSampler(sample_dim=dim)
+    lobe_e = float(r.choice([5, 25, 100]))
+    lobe = MultiJitteredSampler(sample_dim=2, e=lobe_e)
+    world.viewplane = ViewPlane(resolution=(96, 64), pixel_size=3.3, sampler=sampler)
+    angle = float(r.uniform(0, 2 * numpy.pi))
+    eye = (float(round(9 * numpy.cos(angle), 3)), float(round(r.uniform(2, 6), 3)), float(round(9 * numpy.sin(angle), 3)))
+    world.camera = PinholeCamera(eye=eye, up=(0., 1., 0.), lookat=(0., 1.2, 0.), viewing_distance=330.)
+    world.background_color = numpy.array([float(x) for x in numpy.round(r.uniform(0, .2, 3), 2)])
+    world.tracer = (Tracer(world, int(r.randint(1, 4))), AreaLightTracer(world), WhittedTracer(world, 2))[kind]
+    if r.rand() < 0.6:
+        world.ambient_color = AmbientOccluder(numpy.array((1., 1., 1.)), float(round(r.uniform(.2, .6), 2)), sampler)
+    else:
+        world.ambient_color = AmbientLight(_colour(r), float(round(r.uniform(.1, .4), 2)))
+
+    with open('meshes/teapot.obj') as f:
+        mesh = read_mesh(f)
+    if r.rand() < 0.5:
+        mesh.compute_smooth_normal()
+    mesh.material = _material(r, kind, lobe, lobe_e)
+    boxes = mesh.get_bounding_boxes()
+    if r.rand() < 0.4:
+        for box in boxes[::int(r.randint(3, 9))]:
+            box.obj.cast_shadow = False
+    pot = KDTree(BoundingBoxes(boxes))
+    wrap = int(r.randint(0, 3))
+    if wrap >= 1:
+        pot = Instance(pot, _transform(r, (0., 0., 0.)))
+    if wrap == 2:
+        pot = Instance(pot, transform.translate(float(r.uniform(-1, 1)), 0.2, float(r.uniform(-1, 1))))
+    objects = [Plane(origin=(0, 0, 0), normal=(0, 1, 0), material=_material(r, min(kind, 1), lobe, lobe_e)), pot]
+    for _ in range(int(r.randint(0, 3))):
+        where = _vec(r, -4, 4) * numpy.array((1., 0., 1.)) + numpy.array((0., float(r.uniform(.4, 2.0)), 0.))
+        objects.append(Sphere(center=where, radius=float(round(r.uniform(.4, 1.0), 2)), material=_material(r, kind, lobe, lobe_e)))
+    lights = []
+    if kind == 1:
+        glow = Emissive(float(round(r.uniform(5, 12), 1)), _colour(r))
+        # half of the panels hang low and close: their rays end inside the teapot's box
+        height = float(r.uniform(1.0, 2.5)) if r.rand() < 0.5 else float(r.uniform(5, 8))
+        panel = Rectangle(numpy.array((float(r.uniform(-2, 0)), height, float(r.uniform(-3, -1.5)))),
+                          float(r.choice([1, 2])), float(r.choice([1, 2])),
+                          numpy.array((0., 0., 1.)), numpy.array((0., 1., 0.)), glow, sampler)
+        panel.cast_shadow = False
+        objects.append(panel)
+        lights.append(AreaLight(glow, panel, float(r.choice([3., 5.]))))
+    else:
+        for _ in range(int(r.randint(1, 4))):
+            if r.rand() < 0.6:
+                inside = r.rand() < 0.5
+                where = _vec(r, -1.5, 1.5) * numpy.array((1., 0., 1.)) + numpy.array((0., float(r.uniform(1.0, 2.8) if inside else r.uniform(5, 9)), 0.))
+                lights.append(PointLight(_colour(r), float(round(r.uniform(.8, 2.0), 2)), where,
+                                         radius=float(r.choice([5, 8])), attenuation=int(r.choice([0, 2])),
+                                         cast_shadow=True))
+            else:
+                lights.append(DirectionLight(_colour(r), float(round(r.uniform(.3, 1.0), 2)),
+                                             _vec(r, -1, 1) * numpy.array((1., 0., 1.)) + numpy.array((0., float(r.uniform(.3, 1.)), 0.)),
+                                             True))
+    world.objects = objects
+    world.lights = lights
+
+
+def _make_mesh(k):
+    class FuzzMesh(BuildFunctionBase):
+        BUILD_FUNCTION_NAME = 'fuzzmesh_%d' % k
+
+        @classmethod
+        def build_function(cls, world, viewmode):
+            build_mesh_world(world, viewmode, k)
+    FuzzMesh.__name__ = 'FuzzMesh%d' % k
+    return FuzzMesh
+
+
+MESH_WORLDS = [_make_mesh(k) for k in range(N_MESH_WORLDS)]

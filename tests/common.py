@@ -13,6 +13,7 @@ GOLDEN_SCENES = ("foursphere", "glossyreflective", "mirrorhall", "mirrorhall_dof
                  "features_pane", "features_pile", "features_texture", "glass_teapot", "j", "dragon_area",
                  "k", "mirror", "mirroralt", "features_nested",
                  "fuzz_0", "fuzz_1", "fuzz_2", "fuzz_3", "fuzz_4", "fuzz_5", "fuzz_6", "fuzz_7", "fuzz_8",
+                 "fuzzmesh_0", "fuzzmesh_1", "fuzzmesh_2", "fuzzmesh_10",
                  "glossyreflective@realtime", "mirrorhall@realtime")
 
 # float comparison bound for radiance: the tolerance of the task statement is 1e-4

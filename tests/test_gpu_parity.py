@@ -64,6 +64,18 @@ def test_random_worlds_match_oracle(torch_gpu, first):
         check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), 96, None, "fuzz_%d" % k)
 
 
+@pytest.mark.parametrize("first", range(0, 12, 4))
+def test_random_teapot_worlds_match_oracle(torch_gpu, first):
+    """Twelve seeded worlds around the teapot's kd-tree (`fuzzmesh_<k>`, raytracer_amd/scenes/fuzz.py):
+    a mesh with a shadow tree under every tracer, bare and instanced, smooth and flat, with
+    triangles that cast no shadow, lights inside and outside its box.  Whole frames, every sample."""
+    from raytracer_amd import flatten
+    from raytracer_amd.world import World
+    for k in range(first, first + 4):
+        world = World(viewmode="parallel", buildfunction="fuzzmesh_%d" % k, seed=1)
+        check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), 96, None, "fuzzmesh_%d" % k)
+
+
 def check_tiles_against_oracle(torch, world, flat, tiles, samples, scene):
     from raytracer_amd import flatten, runtime
     from oracle import oracle
