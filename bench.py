@@ -140,6 +140,12 @@ def main():
         # process per GPU, lets rank 0's JSON line through and leaves with their status
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries the one JSON line and nothing else: whatever a library prints to file
+    # descriptor 1 from here on (collective back ends announce their connections there) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     pmc, pmc_source = None, None
     if args.gpus == 1 and not args.pmc_probe and not os.environ.get("RTAMD_BENCH_LAUNCH_ONLY"):
         pmc, pmc_source = profile_counters(args, log)
@@ -166,7 +172,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"launch_only": True, "n_gpus": world_size, "rank_sum": int(seen[0])}), flush=True)
+            json_out.write(json.dumps({"launch_only": True, "n_gpus": world_size, "rank_sum": int(seen[0])}) + "\n")
+            json_out.flush()
         return
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
@@ -319,7 +326,8 @@ def main():
                                  "traffic for the same rays, most of which the kernel culls - not a rate it reaches"},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if world_size > 1:
         dist.destroy_process_group()
 
