@@ -473,6 +473,23 @@ int rtamd_kd_build_static(const double *box_lo, const double *box_hi, int64_t n_
 /* Message of the calling thread's last failed rtamd_kd_* call. */
 const char *rtamd_kd_last_error(void);
 
+/* Builds a shadow tree (rtamd_tree.shadow_root) on the host: a kd-tree over n_boxes triangle
+ * boxes (box_lo / box_hi [n_boxes][3], host memory, already widened as rtamd_tree.shadow_root
+ * asks) by the surface-area heuristic over the box faces; a box that straddles a plane goes to
+ * both sides; a node of at most leaf_rows boxes, or one that no plane improves, becomes a leaf.
+ * No counterpart in the reference, whose kdtree.py builds the tree its own walk needs; this is
+ * the tree for shadow queries that any hit decides.
+ * Nodes come back in preorder (left child = next node): node_axis 0..2 with node_split and
+ * node_link = index of the right child, or node_axis -1 for a leaf whose number is node_link;
+ * leaf k holds the boxes leaf_row[leaf_offset[k] .. leaf_offset[k+1]).  With the five output
+ * arrays NULL only the sizes are worked out (n_nodes, n_leaves, n_rows, depth = levels).
+ * RTAMD_EUNSUPPORTED: within max_depth levels some leaf would keep more than max_leaf_rows. */
+int rtamd_shadow_tree_build(const double *box_lo, const double *box_hi, int64_t n_boxes, int32_t max_depth,
+                            int32_t leaf_rows, int32_t max_leaf_rows, double step_cost,
+                            int32_t *node_axis, double *node_split, int32_t *node_link, int64_t max_nodes,
+                            int64_t *leaf_offset, int32_t *leaf_row, int64_t max_rows,
+                            int64_t *n_nodes, int64_t *n_leaves, int64_t *n_rows, int32_t *depth);
+
 #ifdef __cplusplus
 }
 #endif

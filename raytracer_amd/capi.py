@@ -109,7 +109,8 @@ class SampleOut(C.Structure):
 EXPORTS = ("rtamd_abi_version", "rtamd_device_check", "rtamd_last_error",
            "rtamd_scene_create", "rtamd_scene_destroy", "rtamd_render_pixels",
            "rtamd_trace_rays", "rtamd_render_tiles",
-           "rtamd_kd_build_workspace_bytes", "rtamd_kd_build", "rtamd_kd_build_static", "rtamd_kd_last_error")
+           "rtamd_kd_build_workspace_bytes", "rtamd_kd_build", "rtamd_kd_build_static", "rtamd_kd_last_error",
+           "rtamd_shadow_tree_build")
 
 
 class KdTreeOut(C.Structure):
@@ -151,6 +152,9 @@ def bind(lib):
                                           C.POINTER(i32), vp]
     lib.rtamd_kd_last_error.restype = C.c_char_p
     lib.rtamd_kd_last_error.argtypes = []
+    lib.rtamd_shadow_tree_build.restype = C.c_int
+    lib.rtamd_shadow_tree_build.argtypes = [vp, vp, i64, i32, i32, i32, C.c_double, vp, vp, vp, i64, vp, vp, i64,
+                                            C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]
     return lib
 
 

@@ -69,60 +69,44 @@ AUX_DEPTH = 16      # levels a shadow subtree may have (fewer below a deep leaf)
 
 def _shadow_subtree(lo, hi, max_depth):
     """A kd-tree over the (padded) triangle boxes lo, hi [n, 3], for queries that any hit
-    decides: surface-area heuristic over the box faces, triangles whose box straddles a plane
-    go to both sides.  Returns (records, leaves, levels): records in preorder as (axis, split,
-    index of the right child) or (-1, leaf number, 0), and the row numbers (into lo / hi) of
-    every leaf; None when some leaf would keep more than AUX_MAX_LEAF rows within max_depth
-    levels."""
-    records, leaves, reached = [], [], [0]
-    inf = numpy.inf
+    decides (rtamd_shadow_tree_build in csrc/rt_shadowtree.cpp: surface-area heuristic over the
+    box faces, triangles whose box straddles a plane go to both sides).  Returns (axis, split,
+    link, leaf_offset, leaf_row, levels): nodes in preorder, axis -1 for a leaf whose number is
+    link, else link = index of the right child; leaf k holds rows leaf_row[leaf_offset[k] :
+    leaf_offset[k + 1]] (numbers into lo / hi).  None when some leaf would keep more than
+    AUX_MAX_LEAF rows within max_depth levels."""
+    lib = capi.library()
+    lo = numpy.ascontiguousarray(lo, dtype=numpy.float64)
+    hi = numpy.ascontiguousarray(hi, dtype=numpy.float64)
+    n_nodes, n_leaves, n_rows, levels = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
 
-    def build(idx, cell_lo, cell_hi, depth):
-        n = len(idx)
-        me = len(records)
-        best = None
-        if depth > reached[0]:
-            reached[0] = depth
-        if n > AUX_LEAF and depth < max_depth:
-            l, h = lo[idx], hi[idx]
-            cand = numpy.concatenate([l, h])
-            sorted_lo, sorted_hi = numpy.sort(l, axis=0), numpy.sort(h, axis=0)
-            d = cell_hi - cell_lo
-            whole = max(d[0] * d[1] + d[1] * d[2] + d[2] * d[0], 1e-300)
-            for axis in range(3):
-                c = cand[:, axis]
-                n_left = numpy.searchsorted(sorted_lo[:, axis], c, side="left")         # boxes with lo < plane
-                n_right = n - numpy.searchsorted(sorted_hi[:, axis], c, side="right")    # boxes with hi > plane
-                d1, d2 = d[(axis + 1) % 3], d[(axis + 2) % 3]
-                # surface of a box that is x long on this axis: x * (d1 + d2) + d1 * d2
-                cost = AUX_STEP_COST + (((c - cell_lo[axis]) * (d1 + d2) + d1 * d2) * n_left
-                                        + ((cell_hi[axis] - c) * (d1 + d2) + d1 * d2) * n_right) / whole
-                cost[(c <= cell_lo[axis]) | (c >= cell_hi[axis]) | ((n_left == n) & (n_right == n))] = inf
-                k = int(numpy.argmin(cost))
-                if cost[k] < (inf if best is None else best[0]):
-                    best = (float(cost[k]), axis, float(c[k]))
-        if best is None or (best[0] >= n and n <= AUX_MAX_LEAF):
-            if n > AUX_MAX_LEAF:
-                raise OverflowError
-            records.append((-1, len(leaves), 0))
-            leaves.append(idx)
-            return
-        _, axis, plane = best
-        records.append(None)
-        left, right = idx[lo[idx, axis] < plane], idx[hi[idx, axis] > plane]
-        lh, rl = cell_hi.copy(), cell_lo.copy()
-        lh[axis] = plane
-        rl[axis] = plane
-        build(left, cell_lo, lh, depth + 1)
-        right_at = len(records)
-        build(right, rl, cell_hi, depth + 1)
-        records[me] = (axis, plane, right_at)
+    def call(axis, split, link, offsets, rows, max_nodes, max_rows):
+        return lib.rtamd_shadow_tree_build(
+            lo.ctypes.data, hi.ctypes.data, len(lo), int(max_depth), AUX_LEAF, AUX_MAX_LEAF, AUX_STEP_COST,
+            axis, split, link, max_nodes, offsets, rows, max_rows,
+            C.byref(n_nodes), C.byref(n_leaves), C.byref(n_rows), C.byref(levels))
 
-    try:
-        build(numpy.arange(len(lo)), lo.min(axis=0), hi.max(axis=0), 0)
-    except OverflowError:
-        return None
-    return records, leaves, reached[0]
+    max_nodes, max_rows = 2 * len(lo) + 64, 6 * len(lo) + 1024           # usually enough; the sizes come back either way
+    for _ in range(2):
+        axis = numpy.empty(max_nodes, dtype=numpy.int32)
+        split = numpy.empty(max_nodes, dtype=numpy.float64)
+        link = numpy.empty(max_nodes, dtype=numpy.int32)
+        offsets = numpy.empty(max_nodes + 1, dtype=numpy.int64)
+        rows = numpy.empty(max_rows, dtype=numpy.int32)
+        status = call(axis.ctypes.data, split.ctypes.data, link.ctypes.data, offsets.ctypes.data, rows.ctypes.data,
+                      max_nodes, max_rows)
+        if status == capi.EUNSUPPORTED:
+            return None
+        if status == 0:
+            break
+        if n_nodes.value <= max_nodes and n_rows.value <= max_rows:
+            raise RuntimeError("rtamd_shadow_tree_build failed (%d)" % status)
+        max_nodes, max_rows = n_nodes.value, n_rows.value
+    else:
+        raise RuntimeError("rtamd_shadow_tree_build failed (%d)" % status)
+    axis, split, link = axis[:n_nodes.value], split[:n_nodes.value], link[:n_nodes.value]
+    offsets = offsets[:n_leaves.value + 1]
+    return axis, split, link, offsets, rows[:n_rows.value], int(levels.value)
 
 
 def device_arrays(flat):
@@ -252,22 +236,29 @@ def _device_arrays(flat):
             built = _shadow_subtree(blo, bhi, room)
             if built is None:
                 return None
-            records, sub_leaves, levels = built
+            axis, split, link, offsets, rows_of, levels = built
             root = next_node[0]
-            for rec in records:
-                box = numpy.zeros(8, dtype=numpy.float32)
-                if rec[0] < 0:
-                    rows_here = sub_leaves[rec[1]]
-                    extra_nodes.append((-1.0, next_row[0], (len(rows_here) << 2) | 3))
-                    if len(rows_here):
-                        l32, h32 = _boxes_f32(blo[rows_here].min(axis=0)[None, :], bhi[rows_here].max(axis=0)[None, :])
-                        box[0:3], box[3:6] = l32[0], h32[0]
-                    extra_rows.append(src_rows[rows_here])
-                    next_row[0] += len(rows_here)
-                else:
-                    extra_nodes.append((rec[1], root + rec[2], rec[0]))
-                extra_boxes.append(box)
-            next_node[0] += len(records)
+            more = numpy.zeros(len(axis), dtype=nodes.dtype)
+            is_leaf = axis < 0
+            counts_here = numpy.diff(offsets)[link[is_leaf]]
+            more["split"] = numpy.where(is_leaf, -1.0, split)
+            more["a"][~is_leaf] = root + link[~is_leaf]
+            more["b"][~is_leaf] = axis[~is_leaf]
+            more["a"][is_leaf] = next_row[0] + offsets[:-1][link[is_leaf]]
+            more["b"][is_leaf] = (counts_here.astype(numpy.int32) << 2) | 3
+            boxes32 = numpy.zeros((len(axis), 8), dtype=numpy.float32)
+            filled = numpy.nonzero(numpy.diff(offsets) > 0)[0]                     # leaves that hold rows
+            if len(filled):
+                leaf_lo = numpy.minimum.reduceat(blo[rows_of], offsets[:-1][filled], axis=0)
+                leaf_hi = numpy.maximum.reduceat(bhi[rows_of], offsets[:-1][filled], axis=0)
+                node_of_leaf = numpy.nonzero(is_leaf)[0][numpy.argsort(link[is_leaf])]
+                l32, h32 = _boxes_f32(leaf_lo, leaf_hi)
+                boxes32[node_of_leaf[filled], 0:3], boxes32[node_of_leaf[filled], 3:6] = l32, h32
+            extra_nodes.append(more)
+            extra_boxes.append(boxes32)
+            extra_rows.append(src_rows[rows_of])
+            next_row[0] += len(rows_of)
+            next_node[0] += len(axis)
             return root, levels
 
         whole = set()
@@ -300,9 +291,8 @@ def _device_arrays(flat):
             tree_recs[tree].depth = max(tree_recs[tree].depth, int(level[node]) + got[1])
             la32[node, 6] = numpy.array([got[0]], dtype=numpy.int32).view(numpy.float32)[0]
         if extra_nodes:
-            more = numpy.array(extra_nodes, dtype=nodes.dtype)
-            nodes = numpy.concatenate([nodes, more])
-            la32 = numpy.concatenate([la32, numpy.array(extra_boxes, dtype=numpy.float32)])
+            nodes = numpy.concatenate([nodes] + extra_nodes)
+            la32 = numpy.concatenate([la32] + extra_boxes)
             src = numpy.concatenate(extra_rows) if extra_rows else numpy.zeros(0, dtype=numpy.int64)
             geom = numpy.concatenate([geom, geom[:, src]], axis=1)
             prim = numpy.concatenate([prim, prim[src]])

@@ -45,3 +45,54 @@ def test_product_does_not_import_the_checker(repo_root):
             if f.endswith((".py", ".h", ".hip", ".c", ".cpp")):
                 text = open(os.path.join(base, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), "%s mentions the oracle" % os.path.join(base, f)
+
+
+def test_shadow_tree_builder_on_the_host():
+    """rtamd_shadow_tree_build is host code: sizes, capacity errors, the leaf limit, and the
+    property its trees exist for - every box is listed in every leaf whose cell it reaches into."""
+    import ctypes as C
+    import numpy
+    from raytracer_amd import capi
+    lib = capi.library()
+    rng = numpy.random.RandomState(3)
+    lo = rng.uniform(-1, 1, (500, 3))
+    hi = lo + rng.uniform(0.01, 0.3, (500, 3))
+    n_nodes, n_leaves, n_rows, depth = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+
+    def call(lo, hi, max_depth, leaf, max_leaf, out=None):
+        args = [None] * 3 + [0] + [None] * 2 + [0]
+        if out is not None:
+            axis, split, link, offsets, rows = out
+            args = [axis.ctypes.data, split.ctypes.data, link.ctypes.data, len(axis), offsets.ctypes.data, rows.ctypes.data, len(rows)]
+        return lib.rtamd_shadow_tree_build(lo.ctypes.data, hi.ctypes.data, len(lo), max_depth, leaf, max_leaf, 1.0, *args,
+                                           C.byref(n_nodes), C.byref(n_leaves), C.byref(n_rows), C.byref(depth))
+    assert call(lo, hi, 30, 8, 64) == 0                                   # sizes only
+    sizes = (n_nodes.value, n_leaves.value, n_rows.value, depth.value)
+    assert sizes[0] == 2 * sizes[1] - 1 and sizes[2] >= 500 and 0 < sizes[3] <= 30
+    small = (numpy.zeros(4, numpy.int32), numpy.zeros(4), numpy.zeros(4, numpy.int32), numpy.zeros(5, numpy.int64), numpy.zeros(4, numpy.int32))
+    assert call(lo, hi, 30, 8, 64, small) == -1 and (n_nodes.value, n_rows.value) == (sizes[0], sizes[2])   # too small: sizes come back
+    out = (numpy.zeros(sizes[0], numpy.int32), numpy.zeros(sizes[0]), numpy.zeros(sizes[0], numpy.int32),
+           numpy.zeros(sizes[1] + 1, numpy.int64), numpy.zeros(sizes[2], numpy.int32))
+    assert call(lo, hi, 30, 8, 64, out) == 0
+    axis, split, link, offsets, rows = out
+    todo = [(0, lo.min(axis=0), hi.max(axis=0), numpy.arange(500))]
+    seen = numpy.zeros(500, dtype=bool)
+    while todo:
+        at, cell_lo, cell_hi, members = todo.pop()
+        if axis[at] < 0:
+            got = rows[offsets[link[at]]:offsets[link[at] + 1]]
+            assert sorted(got) == sorted(members) and len(got) <= 64
+            seen[members] = True
+            continue
+        ax, plane = int(axis[at]), float(split[at])
+        assert cell_lo[ax] < plane < cell_hi[ax] and link[at] > at + 1
+        left_hi, right_lo = cell_hi.copy(), cell_lo.copy()
+        left_hi[ax] = right_lo[ax] = plane
+        todo.append((at + 1, cell_lo, left_hi, members[lo[members, ax] < plane]))
+        todo.append((int(link[at]), right_lo, cell_hi, members[hi[members, ax] > plane]))
+    assert seen.all()
+    # a hundred boxes no plane can tell apart, with room for 64 per leaf
+    same_lo, same_hi = numpy.tile(lo[:1], (100, 1)), numpy.tile(hi[:1], (100, 1))
+    assert call(same_lo, same_hi, 30, 8, 64) == capi.EUNSUPPORTED
+    assert call(same_lo, same_hi, 30, 8, 128) == 0 and (n_nodes.value, n_leaves.value, n_rows.value) == (1, 1, 100)
+    assert call(lo, hi, 30, 0, 64) == -1 and call(lo, hi, -1, 8, 64) == -1 and call(lo, hi, 30, 16, 8) == -1

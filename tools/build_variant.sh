@@ -5,4 +5,4 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off ${RT_SCOPE:--DRT_ONLY_HOT} "$@" \
-    -o raytracer_amd/csrc/librtamd_$name.so raytracer_amd/csrc/rt_kernels.hip raytracer_amd/csrc/rt_kdbuild.hip
+    -o raytracer_amd/csrc/librtamd_$name.so raytracer_amd/csrc/rt_kernels.hip raytracer_amd/csrc/rt_kdbuild.hip raytracer_amd/csrc/rt_shadowtree.cpp

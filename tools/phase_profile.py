@@ -26,7 +26,8 @@ def build():
     import __graft_entry__ as entry
     src = os.path.join(REPO, "raytracer_amd", "csrc", "rt_kernels.hip")
     kd = os.path.join(REPO, "raytracer_amd", "csrc", "rt_kdbuild.hip")
-    cmd = ["/opt/rocm/bin/hipcc"] + entry.HIP_FLAGS + ["-DRT_PHASE_TIMERS", "-DRT_ONLY_TILES", "-I", os.path.join(REPO, "include"), src, kd, "-o", LIB]
+    st = os.path.join(REPO, "raytracer_amd", "csrc", "rt_shadowtree.cpp")
+    cmd = ["/opt/rocm/bin/hipcc"] + entry.HIP_FLAGS + ["-DRT_PHASE_TIMERS", "-DRT_ONLY_TILES", "-I", os.path.join(REPO, "include"), src, kd, st, "-o", LIB]
     subprocess.check_call(cmd)
 
 
