@@ -39,9 +39,10 @@ enum { MODE_PIXELS = 0, MODE_RAYS = 1, MODE_TILES = 2 };
 #endif
 #ifndef RT_GROUP_SHIFT_MAX
 // Tile mode: a wave takes up to 2^RT_GROUP_SHIFT_MAX samples of each of its pixels (see the
-// kernel).  1080p dragon frame, 16 samples per pixel: 8x8 pixels x 1 sample 16.41 ms,
-// 4x4 x 4 -> 15.70 ms, 2x2 x 16 -> 16.57 ms.
-#define RT_GROUP_SHIFT_MAX 2
+// kernel).  1080p dragon frame, 16 samples per pixel: 8x8 pixels x 1 sample 8.61 ms,
+// 4x4 x 4 -> 7.90 ms, 2x2 x 16 -> 7.69 ms (before the shadow rays had a tree of their own the
+// middle one was best: 16.41 / 15.70 / 16.57 ms).
+#define RT_GROUP_SHIFT_MAX 4
 #endif
 constexpr int BLOCK = RT_BLOCK;
 static_assert(BLOCK == 64, "the LDS traversal stack is sized for one wave per workgroup");
