@@ -2015,10 +2015,23 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(rt_pow<false>(b.x
 // the compiler then drops the bounce loop and the ray and weight it would carry through the
 // shadow queries.  The instantiation is launched for scenes with exactly one kd-tree object,
 // which the shadow tests then ask last (occluded_wave<..., ONE_TREE>), and exactly one light.
-template <int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
+// FEED: where a lane whose path has ended hands its sample in and takes another one, so that the
+// wave's lanes stay filled while paths of different lengths end at different bounces (the kernels
+// that own a list of samples per wave pass one; NoFeed: a lane traces one sample).
+struct NoFeed {
+    static constexpr bool on = false;
+    __device__ __forceinline__ void retire(V3) {}
+    __device__ __forceinline__ bool next(bool, Ray&, Draw&) { return false; }
+    __device__ __forceinline__ bool more() const { return false; }
+};
+
+template <int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, class FEED = NoFeed>
 __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
-                         Work<COUNT>& w, Primary& first) {
+                         Work<COUNT>& w, Primary& first, FEED& feed) {
+    static_assert(!FEED::on || (!EXT && !AREA_ONLY), "sample feeds serve the plain bounce loop");
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
+    const int depth0 = depth;
+    bool busy = alive;                      // FEED: the lane holds a sample that is not handed in yet
     const int tracer_kind = AREA_ONLY ? (int)RTAMD_TRACER_AREA : S.tracer_kind;
     const bool shade_kind = tracer_kind == RTAMD_TRACER_SHADE || tracer_kind == RTAMD_TRACER_WHITTED;
     const V3 background = shade_kind ? ld3(S.background) : v3(0, 0, 0);
@@ -2040,6 +2053,17 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
             }
             if (alive && !area && lane_depth > S.depth_limit) { L = L + W * background; alive = false; }
             if (!__ballot(alive || n_pending > 0)) break;
+        } else if (FEED::on) {
+            if (alive && !area && lane_depth > S.depth_limit) { L = L + W * background; alive = false; }
+            if (!alive && busy) { feed.retire(L); busy = false; }
+            if (feed.next(!alive, ray, dr)) {
+                alive = true; busy = true;
+                L = v3(0, 0, 0); W = v3(1, 1, 1);
+                lane_depth = depth0;
+            }
+            // (a sample of a pixel outside the image is nothing to trace: such a lane asks again in the
+            // next pass, and a wave left without a live lane that way goes round once more)
+            if (!__ballot(alive) && !feed.more()) break;
         } else {
             if (alive && !area && depth > S.depth_limit) { L = L + W * background; alive = false; }
             if (!__ballot(alive)) break;
@@ -2047,6 +2071,7 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
         Hit h;
         h.p = v3(0, 0, 0); h.n = v3(0, 0, 1); h.material = 0;
         w.mark(32);     // ray generation / previous bounce
+        // (with a feed, primary rays taken in later join lanes whose rays have bounced: only the first pass is coherent)
         const bool hit = closest_hit_wave<COUNT, TREES>(S, stk, alive, primary, ray, w, h);
         w.mark(31);     // closest hit, kd query included
         if (alive && !hit) { L = L + W * background; alive = false; }

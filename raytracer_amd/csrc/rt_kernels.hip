@@ -33,6 +33,14 @@ enum { MODE_PIXELS = 0, MODE_RAYS = 1, MODE_TILES = 2 };
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
+#ifndef RT_REFILL_MAX
+// 64-sample groups of the work list per wave of refill_kernel: the largest divisor of the samples
+// per pixel up to this.  glossyreflective 400x400x100 (the divisor in brackets): off 3.19 ms,
+// 4 [4] 2.30, 8 [5] 1.93, 16 [10] 1.15, 32 [25] 1.44 ms; mirror hall 4K x 64: off 104.5 ms,
+// 4 83.3, 8 82.4, 16 81.8, 32 82.1 ms.  Longer lists shorten the share of a wave's life in which
+// its last paths run on with few lanes, but leave fewer waves to fill the machine with.
+#define RT_REFILL_MAX 16
+#endif
 #ifndef RT_MIN_WAVES_ANALYTIC
 // waves per SIMD the kernels for scenes without a kd-tree are held to (they need no traversal state)
 #define RT_MIN_WAVES_ANALYTIC 4
@@ -59,6 +67,7 @@ struct LaunchArgs {
     int32_t depth0;
     int32_t sample_begin, n_samples, tiles_x;
     int32_t group_shift;        // tile mode: log2 of the samples of one pixel that share a wave (0, 2, 4 or 6)
+    int32_t refill;             // refill_kernel: 64-sample groups of the work list one wave owns
     int64_t seg_len;            // tile mode: waves per XCD segment, 0 = no remap
     rtamd_sample_out out;
     int64_t* sum_rgb8;
@@ -212,7 +221,8 @@ __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC
         stk.node = stack_node;
         stk.t = stack_t;
         stk.slot = stack_slot;
-const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, live, ray, A.depth0, dr, work, first);
+        NoFeed no_feed;
+        const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, live, ray, A.depth0, dr, work, first, no_feed);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
             if (!AREA_ONLY) {
@@ -288,6 +298,102 @@ const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, live, ray, A.depth
     }
 }
 
+// The samples one wave of refill_kernel owns, handed to its lanes as their paths end.  Paths of
+// a scene of mirrors and glossy surfaces end after different numbers of bounces; a lane that is
+// done hands its sample in (per-pixel sums in LDS) and takes the next one of the wave's list, so
+// later bounces run with full vectors instead of the few lanes whose paths go on.  Which lane
+// traces a sample does not enter its colour: every draw is keyed by (pixel, sample, position in
+// the sample's own draw sequence).
+struct TileFeed {
+    static constexpr bool on = true;
+    const rtamd_scene_desc& S;
+    const LaunchArgs& A;
+    int64_t next_k, end_k;                  // wave-uniform: the part of the list not handed out yet
+    unsigned long long* bins;               // LDS [64][3]: int(c*255) sums per pixel of the tile
+    double* sq;                             // LDS [64][3]: c*c sums
+    int32_t bin;                            // the lane's current pixel in its tile
+    uint32_t taken = 0;                     // samples this lane has traced or is tracing
+
+    __device__ __forceinline__ void retire(V3 c) {
+        if (A.sum_rgb8) {
+            atomicAdd(&bins[3 * bin], (unsigned long long)(long long)quantise(c.x));
+            atomicAdd(&bins[3 * bin + 1], (unsigned long long)(long long)quantise(c.y));
+            atomicAdd(&bins[3 * bin + 2], (unsigned long long)(long long)quantise(c.z));
+        }
+        if (A.sum_sq) {
+            atomicAdd(&sq[3 * bin], c.x * c.x);
+            atomicAdd(&sq[3 * bin + 1], c.y * c.y);
+            atomicAdd(&sq[3 * bin + 2], c.z * c.z);
+        }
+    }
+    __device__ __forceinline__ bool more() const { return next_k < end_k; }
+    // all lanes call; lanes with `want` are given consecutive samples by their rank among them
+    __device__ __forceinline__ bool next(bool want, Ray& ray, Draw& dr) {
+        const unsigned long long m = __ballot(want);
+        if (!m || next_k >= end_k) return false;
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const int64_t k = next_k + rank;
+        next_k += __popcll(m);
+        if (!want || k >= end_k) return false;
+        return start(k, ray, dr);
+    }
+    __device__ __forceinline__ bool start(int64_t k, Ray& ray, Draw& dr) {
+        int32_t pixel = 0, sample = 0;
+        int64_t acc_row = 0, ko = 0;
+        if (!tile_ray(S, A, k, ray, pixel, sample, acc_row, ko)) return false;     // a pixel outside the image
+        bin = (int32_t)(acc_row & 63);
+        dr.key = mix64(A.trace_key ^ (uint64_t)(uint32_t)pixel);
+        dr.sample = (uint32_t)sample;
+        dr.counter = 0;
+        taken++;
+        return true;
+    }
+};
+
+// Whole frames of scenes without a kd-tree, accumulators only: a wave owns A.refill consecutive
+// 64-sample groups of the tile work list (all of one tile: A.refill divides the samples per
+// pixel), starts on the first and refills lanes from the others (TileFeed).  Sums per pixel are
+// kept in LDS and added to the accumulators once per pixel, channel and wave.
+template <int COUNT>
+__global__ __launch_bounds__(BLOCK, RT_MIN_WAVES_ANALYTIC) void refill_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
+    __shared__ unsigned long long bins[192];
+    __shared__ double sq[192];
+    const int lane = (int)threadIdx.x;
+    for (int i = lane; i < 192; i += BLOCK) { bins[i] = 0; sq[i] = 0.0; }
+    __syncthreads();
+    const int64_t k0 = (int64_t)blockIdx.x * BLOCK * A.refill;
+    TileFeed feed{S, A, k0 + BLOCK, min(k0 + (int64_t)BLOCK * A.refill, A.n), bins, sq, 0};
+    Ray ray;
+    ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1);
+    Draw dr;
+    dr.key = 0; dr.sample = 0; dr.counter = 0;
+    const bool live = k0 + lane < A.n && feed.start(k0 + lane, ray, dr);
+    Work<COUNT> work;
+    Primary first;
+    KdStack stk;
+    stk.node = nullptr; stk.t = nullptr; stk.slot = nullptr;     // no kd-tree, no traversal stack
+    trace_wave<COUNT, false, false, false, TileFeed>(S, stk, live, ray, A.depth0, dr, work, first, feed);
+    __syncthreads();
+    // lane l adds the sums of pixel l of the wave's tile (zero where the wave traced nothing)
+    const int64_t acc_row = k0 / ((int64_t)64 * A.n_samples) * 64 + lane;
+    if (A.sum_rgb8) {
+        unsigned long long* s = reinterpret_cast<unsigned long long*>(A.sum_rgb8) + 3 * acc_row;
+        for (int c = 0; c < 3; ++c)
+            if (bins[3 * lane + c]) atomicAdd(s + c, bins[3 * lane + c]);
+    }
+    if (A.sum_sq) {
+        for (int c = 0; c < 3; ++c)
+            if (sq[3 * lane + c] != 0.0) atomicAdd(A.sum_sq + 3 * acc_row + c, sq[3 * lane + c]);
+    }
+    if (A.counters) {
+        unsigned int v[3] = {work.closest, work.shadow, feed.taken};
+        for (int i = 0; i < 3; ++i) {
+            for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+            if (lane == 0 && v[i]) atomicAdd(&A.counters[i], (unsigned long long)v[i]);
+        }
+    }
+}
+
 thread_local char g_error[512] = "";
 
 int fail(int code, const char* fmt, const char* detail = "") {
@@ -320,6 +426,22 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, LaunchArg
     if (count && executed) return fail(RTAMD_EINVAL, "RTAMD_COUNT_WORK and RTAMD_COUNT_EXECUTED exclude each other%s");
     if (executed && !A.counters) return fail(RTAMD_EINVAL, "RTAMD_COUNT_EXECUTED needs a counter block%s");
     const dim3 grid((unsigned)blocks), block(BLOCK);
+#if !defined(RT_NO_REFILL) && !defined(RT_ONLY_HOT)
+    // whole frames of scenes without a kd-tree, accumulators only: waves that refill their lanes
+    if (MODE == MODE_TILES && !trees && !extended && !count && !executed && !A.out.rgb && !A.out.rgb8 && !A.out.hit_object &&
+        !A.out.hit_prim && !A.out.hit_t && !A.out.n_rays) {
+        A.refill = 0;
+        for (int r = RT_REFILL_MAX; r > 1; --r)
+            if (A.n_samples % r == 0) { A.refill = r; break; }
+        if (A.refill > 1) {
+            const int64_t waves = (A.n + (int64_t)BLOCK * A.refill - 1) / ((int64_t)BLOCK * A.refill);
+            hipLaunchKernelGGL((refill_kernel<0>), dim3((unsigned)waves), block, 0, st, S, A);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "kernel launch");
+            return RTAMD_OK;
+        }
+    }
+#endif
     // the whole-frame case of a single tree under the AreaLightTracer with a single light has a kernel of its own
     bool area_only = false;
 #ifndef RT_NO_AREA_ONLY

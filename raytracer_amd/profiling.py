@@ -35,7 +35,7 @@ def rocprofv3_path():
     return shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
 
 
-def collect(command, kernel="trace_kernel", passes=PASSES, timeout_s=240, log=None):
+def collect(command, kernel=("trace_kernel", "refill_kernel"), passes=PASSES, timeout_s=240, log=None):
     """{counter: average per dispatch, "dispatches": n, "vgpr"/"accum_vgpr"/"sgpr"/"scratch"/"lds": ...}
     or None when rocprofv3 is missing or a pass fails."""
     exe = rocprofv3_path()
@@ -63,7 +63,7 @@ def collect(command, kernel="trace_kernel", passes=PASSES, timeout_s=240, log=No
             for path in glob.glob(os.path.join(work, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
                     for row in csv.DictReader(f):
-                        if kernel not in row["Kernel_Name"]:
+                        if not any(k in row["Kernel_Name"] for k in ((kernel,) if isinstance(kernel, str) else kernel)):
                             continue
                         c = row["Counter_Name"]
                         sums[c] = sums.get(c, 0.0) + float(row["Counter_Value"])

@@ -590,6 +590,61 @@ def test_full_size_analytic_frames(torch_gpu, scene, overrides, oracle_tiles):
     common.assert_integer_sums_match(got, want, per["rgb"], len(pick), ns, scene)
 
 
+@pytest.mark.parametrize("scene,sample_dim", [("glossyreflective", 2), ("glossyreflective", 3), ("glossyreflective", 5),
+                                              ("mirrorhall_dof", 4), ("foursphere", 6), ("features_analytic", 4)])
+def test_refilled_waves_render_the_same_frame(torch_gpu, scene, sample_dim):
+    """Whole frames of scenes without a kd-tree, accumulators only, are rendered by waves that own
+    several 64-sample groups and refill lanes whose paths have ended (where the sample count has a
+    divisor for it; 9 samples have none up to 16 but 3 and 9, 25 have 5); per-sample outputs force
+    the one-sample-per-lane kernel.  Both must agree sample for sample: equal integer sums, equal
+    ray and sample counts, squared sums within rounding, on a frame with partly empty edge tiles
+    and across a split of the sample range."""
+    from raytracer_amd import flatten, runtime
+    torch = torch_gpu
+    import sampler
+    world = _tiny_world(scene, seed=3)
+    world.viewplane.resolution = (44, 30)                  # whatever the scene file chose
+    world.viewplane.sampler = sampler.MultiJitteredSampler(sample_dim)
+    world.invalidate()
+    ds = runtime.device_scene(world)
+    assert len(ds.flat.arrays["trees"]) == 0
+    cam = flatten.camera_record(world)
+    tx, ty = runtime.tile_grid(44, 30)
+    tiles = numpy.arange(tx * ty, dtype=numpy.int32)
+    ns = sample_dim * sample_dim
+    ds.read_counters(reset=True)
+    fb = runtime.FrameBuffers(ds, tiles)
+    ds.render_tiles(cam, world.seed, fb.tile_ids, 0, ns, sum_rgb8=fb.sum_rgb8, sum_sq=fb.sum_sq)
+    torch.cuda.synchronize()
+    fast = ds.read_counters(reset=True)
+    ref = runtime.FrameBuffers(ds, tiles)
+    per = ds.sample_buffers(len(tiles) * 64 * ns, want=("rgb", "rgb8"))
+    ds.render_tiles(cam, world.seed, ref.tile_ids, 0, ns, sum_rgb8=ref.sum_rgb8, sum_sq=ref.sum_sq, per_sample=per)
+    torch.cuda.synchronize()
+    slow = ds.read_counters(reset=True)
+    assert fast == slow and fast["samples"] == 44 * 30 * ns
+    assert torch.equal(fb.sum_rgb8, ref.sum_rgb8)
+    # rows of the per-sample outputs are (tile, sample, pixel in tile)
+    rgb8 = per[0]["rgb8"].reshape(len(tiles), ns, 64, 3).to(torch.int64).sum(dim=1).reshape(-1, 3)
+    assert torch.equal(fb.sum_rgb8, rgb8)
+    assert torch.allclose(fb.sum_sq, ref.sum_sq, rtol=1e-12, atol=1e-300)
+    assert int(fb.sum_rgb8.sum()) > 0
+    # the same samples in two launches (their counts have other divisors)
+    cut = ns // 2 + 1
+    two = runtime.FrameBuffers(ds, tiles)
+    ds.render_tiles(cam, world.seed, two.tile_ids, 0, cut, sum_rgb8=two.sum_rgb8)
+    ds.render_tiles(cam, world.seed, two.tile_ids, cut, ns, sum_rgb8=two.sum_rgb8)
+    torch.cuda.synchronize()
+    assert torch.equal(two.sum_rgb8, fb.sum_rgb8)
+    # a sublist of tiles in another order lands in the rows of that list
+    some = tiles[::-3].copy()
+    part = runtime.FrameBuffers(ds, some)
+    ds.render_tiles(cam, world.seed, part.tile_ids, 0, ns, sum_rgb8=part.sum_rgb8)
+    torch.cuda.synchronize()
+    want = fb.sum_rgb8.reshape(len(tiles), 64, 3)[torch.as_tensor(some.astype(numpy.int64), device=fb.sum_rgb8.device)]
+    assert torch.equal(part.sum_rgb8.reshape(len(some), 64, 3), want)
+
+
 def test_executed_work_counters_on_the_dragon(torch_gpu):
     """RTAMD_COUNT_EXECUTED runs the fast path and tallies it: same frame as the timed kernel, far
     fewer triangle tests than the reference's scan, and loads that add up."""

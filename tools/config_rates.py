@@ -10,6 +10,7 @@ the active lanes per vector instruction.  This parent never touches the GPU."""
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -107,7 +108,7 @@ def main():
                     "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0), 3),
                     "wave_time_waiting": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 3),
                     "valu_insts_per_ray": round(pmc["SQ_INSTS_VALU"] * launches / max(row["rays"], 1), 1),
-                    "kernel": pmc["kernel_name"].split("trace_kernel")[-1].split("(")[0],
+                    "kernel": (re.search(r"\w+_kernel<[^>]*>", pmc["kernel_name"]) or re.search(".*", pmc["kernel_name"])).group(0),
                     "scratch": pmc.get("scratch")})
         rows.append(row)
         print(json.dumps(row), flush=True)
