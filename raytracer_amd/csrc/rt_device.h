@@ -286,7 +286,7 @@ struct PhaseClock {
     __device__ __forceinline__ void count(int) {}
 };
 #endif
-enum { PH_DESCENT = 0, PH_PACK16 = 1, PH_PACK32 = 2, PH_BIG_PLAIN = 3, PH_BIG_BOXES = 4, PH_POP = 5, PH_QUERIES = 6 };
+enum { PH_DESCENT = 0, PH_PACK16 = 1, PH_PACK32 = 2, PH_BIG_PLAIN = 3, PH_BIG_BOXES = 4, PH_POP = 5, PH_QUERIES = 6, PH_HANDOVER = 7 };
 
 // ---------------------------------------------------------------- kd-tree
 // Traversal stack of one wave.  An entry is (far child, t at the split plane); the far
@@ -661,6 +661,7 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
                 }
             }
         }
+        clk.lap(PH_HANDOVER);
 #ifdef RT_PHASE_TIMERS
         {
             const unsigned long long n_walking = __popcll(__ballot(walking));
@@ -915,6 +916,7 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
                 }
             }
         }
+        clk.lap(PH_HANDOVER);
 #ifdef RT_PHASE_TIMERS
         if (SHADOW) {
             // descent rounds and the lanes walking in them

@@ -19,7 +19,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 LIB = os.path.join(REPO, "raytracer_amd", "csrc", "librtamd_phases.so")
-NAMES = ["descent", "pack16", "pack32", "big_plain", "big_boxes", "pop", "queries", "-"]
+NAMES = ["descent", "pack16", "pack32", "big_plain", "big_boxes", "pop", "queries", "handover"]
 
 
 def build():
@@ -64,10 +64,10 @@ def main():
     total, waves = t[16], t[17]
     out = {"workload": args.workload, "frames": args.frames, "waves": waves, "cycles_per_wave": total / max(waves, 1)}
     for base, kind in ((0, "closest"), (8, "shadow_limited"), (36, "shadow_unlimited")):
-        for i, name in enumerate(NAMES[:6]):
-            out["%s_%s" % (kind, name)] = t[base + i] / float(total)
+        for i in (0, 1, 2, 3, 4, 5, 7):
+            out["%s_%s" % (kind, NAMES[i])] = t[base + i] / float(total)
         out["%s_queries_per_wave" % kind] = t[base + 6] / float(max(waves, 1))
-    out["outside_kd_queries"] = 1.0 - sum(t[0:6] + t[8:14] + t[36:42]) / float(total)
+    out["outside_kd_queries"] = 1.0 - sum(t[0:6] + t[7:8] + t[8:14] + t[15:16] + t[36:42] + t[43:44]) / float(total)
     if t[24]:
         out["boxed_shadow_sharing"] = {"episodes": t[24], "rays": t[20], "distinct_leaves": t[21],
                                        "ray_chunk_pairs": t[22], "distinct_leaf_chunk_pairs": t[23]}
