@@ -53,6 +53,7 @@ WORKLOADS = {
     "foursphere_200_1spp": ("foursphere", None),
     "glossyreflective_400_100spp": ("glossyreflective", None),
     "mirrorhall_4k_64spp_dof": ("mirrorhall_dof", dict(resolution=(3840, 2160), sample_dim=8)),
+    "cornellbox_200_100spp_path": ("cornellbox", None),       # the reference's scene file as shipped
 }
 
 
