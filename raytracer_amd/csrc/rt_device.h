@@ -302,6 +302,8 @@ struct KdStack {
     int32_t* node;      // LDS, [LDS_STACK][64]
     double* t;          // LDS, [LDS_STACK][64]
     int32_t* slot;      // LDS, [64]: lane ids by rank while walks are handed over (see kd_query_wave)
+    bool tiny_ok;       // trees of a few levels may be scanned by single lanes throughout (a constant
+                        // false in the kernel that is only launched for deep trees drops that code)
 };
 #define RT_KD_STACK_LDS_BYTES (LDS_STACK * 64 * 12)
 #ifndef RT_SMALL_LEAF
@@ -828,7 +830,7 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
     // a tree of a few levels (the Cornell box: 9 nodes, 68 rows) sits in the L1s whole: there every
     // lane scans the leaves of its own ray, scattered rays and shadow rays too - 64 scans side by
     // side cost less than the wave's packed steps, which serve four rays at a time
-    const bool tiny = T.depth < RT_TINY_DEPTH && S.tri_rows != nullptr;
+    const bool tiny = stk.tiny_ok && T.depth < RT_TINY_DEPTH && S.tri_rows != nullptr;
     const bool lane_scans = !SHADOW && (coherent || tiny) && S.leaf_boxes != nullptr;
     if (SHADOW && COUNT != 1 && T.shadow_casters == RTAMD_CASTERS_NONE) return;
     double t_near = 0, t_far = 0, t_exit = 0;

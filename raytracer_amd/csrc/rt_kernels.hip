@@ -163,7 +163,7 @@ __device__ __forceinline__ bool tile_ray(const rtamd_scene_desc& S, const Launch
 // do not pay for.
 // TREES = false instantiations serve scenes without a kd-tree (analytic primitives only):
 // no traversal code, no LDS stack, and the registers go to the shading loop.
-template <int MODE, int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false>
+template <int MODE, int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, bool TINY_OK = true>
 __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
     // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC
         stk.node = stack_node;
         stk.t = stack_t;
         stk.slot = stack_slot;
+        stk.tiny_ok = TINY_OK;
         NoFeed no_feed;
         const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, live, ray, A.depth0, dr, work, first, no_feed);
         if (live) {
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES_ANALYTIC) void refill_kernel(co
     Primary first;
     KdStack stk;
     stk.node = nullptr; stk.t = nullptr; stk.slot = nullptr;     // no kd-tree, no traversal stack
+    stk.tiny_ok = false;
     trace_wave<COUNT, false, false, false, TileFeed>(S, stk, live, ray, A.depth0, dr, work, first, feed);
     __syncthreads();
     // lane l adds the sums of pixel l of the wave's tile (zero where the wave traced nothing)
@@ -407,7 +409,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 template <int MODE>
-int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, LaunchArgs& A, uint32_t flags, void* stream) {
+int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_tree_depth, LaunchArgs& A, uint32_t flags, void* stream) {
     const bool trees = S.n_trees > 0;
     if (A.n <= 0) return RTAMD_OK;
     A.seg_len = 0;
@@ -442,7 +444,10 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, LaunchArg
         }
     }
 #endif
-    // the whole-frame case of a single tree under the AreaLightTracer with a single light has a kernel of its own
+    // the whole-frame case of a single tree under the AreaLightTracer with a single light has a kernel of its
+    // own, in two builds: one for trees of a few levels (lanes scan their own leaves, kd_query_wave), one
+    // without that code for all others
+    const bool tiny_trees = max_tree_depth < RT_TINY_DEPTH;
     bool area_only = false;
 #ifndef RT_NO_AREA_ONLY
     area_only = MODE == MODE_TILES && !extended && trees && S.tracer_kind == RTAMD_TRACER_AREA && tree_objects == 1 &&
@@ -451,12 +456,13 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, LaunchArg
 #endif
 #ifdef RT_ONLY_HOT
     // experiment builds (tools/variant_bench.sh): only the whole-frame kernel of the benchmark scene
-    if (area_only && !count && !executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
+    if (area_only && !count && !executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
     else return fail(RTAMD_EUNSUPPORTED, "this build holds the whole-frame area-light kernel only%s");
 #elif defined(RT_ONLY_TILES)
     // experiment builds: the uncounted whole-frame kernels only
     if (MODE != MODE_TILES || count || executed) return fail(RTAMD_EUNSUPPORTED, "this build holds the uncounted tile kernels only%s");
     if (extended) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, true, true>), grid, block, 0, st, S, A);
+    else if (area_only && !tiny_trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
     else if (area_only) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
     else if (trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true>), grid, block, 0, st, S, A);
     else hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, false>), grid, block, 0, st, S, A);
@@ -468,6 +474,7 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, LaunchArg
     } else if (trees) {
         if (count) hipLaunchKernelGGL((trace_kernel<MODE, 1, false, true>), grid, block, 0, st, S, A);
         else if (area_only && executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 2, false, true, true>), grid, block, 0, st, S, A);
+        else if (area_only && !tiny_trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
         else if (area_only) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
         else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, false, true>), grid, block, 0, st, S, A);
         else hipLaunchKernelGGL((trace_kernel<MODE, 0, false, true>), grid, block, 0, st, S, A);
@@ -745,7 +752,7 @@ int rtamd_render_pixels(rtamd_scene* scene, const rtamd_camera* camera, uint64_t
     A.b3 = lens_points;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_PIXELS>(scene->desc, scene->extended, scene->tree_objects, A, flags, stream);
+    return launch<MODE_PIXELS>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, A, flags, stream);
 }
 
 int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t* pixel_index,
@@ -770,7 +777,7 @@ int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t
     A.depth0 = depth;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_RAYS>(scene->desc, scene->extended, scene->tree_objects, A, flags, stream);
+    return launch<MODE_RAYS>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, A, flags, stream);
 }
 
 int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t seed, int64_t n_tiles,
@@ -804,7 +811,7 @@ int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t 
     A.sum_rgb8 = sum_rgb8;
     A.sum_sq = sum_sq;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_TILES>(scene->desc, scene->extended, scene->tree_objects, A, flags, stream);
+    return launch<MODE_TILES>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, A, flags, stream);
 }
 
 }  // extern "C"
