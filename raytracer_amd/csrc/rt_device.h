@@ -2022,6 +2022,8 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(rt_pow<false>(b.x
 // depth first in the reference's order - reflected subtree, then the refracted one - with
 // the waiting siblings in a per-lane list (one per level, RTAMD_MAX_BRANCH_LEVELS), so the
 // in-trace draw counter advances exactly as in the recursive formulation.
+// NO_BOUNCE: every material of the scene is Matte, Phong or Emissive under the plain tracer, so no
+// hit spawns a child ray and the body is left after one pass, as under AREA_ONLY.
 // AREA_ONLY: the scene runs under the AreaLightTracer (tracer.py:65-71), which never bounces:
 // the compiler then drops the bounce loop and the ray and weight it would carry through the
 // shadow queries.  The instantiation is launched for scenes with exactly one kd-tree object,
@@ -2036,7 +2038,7 @@ struct NoFeed {
     __device__ __forceinline__ bool more() const { return false; }
 };
 
-template <int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, class FEED = NoFeed>
+template <int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, class FEED = NoFeed, bool NO_BOUNCE = false>
 __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, Primary& first, FEED& feed) {
     static_assert(!FEED::on || (!EXT && !AREA_ONLY), "sample feeds serve the plain bounce loop");
@@ -2126,7 +2128,8 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
         if (alive) L = L + W * Ld;
         // the AreaLightTracer never bounces: leaving here makes the body straight-line code, so
         // nothing is hoisted in front of it and carried (or spilled) through the kd queries
-        if (AREA_ONLY) break;
+        // (NO_BOUNCE: no material of the scene spawns a child ray - the same holds there)
+        if (AREA_ONLY || NO_BOUNCE) break;
         if (area) { alive = false; continue; }
         if (!alive) continue;
 

@@ -163,7 +163,7 @@ __device__ __forceinline__ bool tile_ray(const rtamd_scene_desc& S, const Launch
 // do not pay for.
 // TREES = false instantiations serve scenes without a kd-tree (analytic primitives only):
 // no traversal code, no LDS stack, and the registers go to the shading loop.
-template <int MODE, int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, bool TINY_OK = true>
+template <int MODE, int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, bool TINY_OK = true, bool NO_BOUNCE = false>
 __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
     // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
@@ -223,10 +223,10 @@ __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC
         stk.slot = stack_slot;
         stk.tiny_ok = TINY_OK;
         NoFeed no_feed;
-        const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, live, ray, A.depth0, dr, work, first, no_feed);
+        const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY, NoFeed, NO_BOUNCE>(S, stk, live, ray, A.depth0, dr, work, first, no_feed);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
-            if (!AREA_ONLY) {
+            if (!AREA_ONLY && !NO_BOUNCE) {
             if (A.out.rgb) { A.out.rgb[3 * ko] = c.x; A.out.rgb[3 * ko + 1] = c.y; A.out.rgb[3 * ko + 2] = c.z; }
             if (A.out.rgb8) { A.out.rgb8[3 * ko] = r8; A.out.rgb8[3 * ko + 1] = g8; A.out.rgb8[3 * ko + 2] = b8; }
             if (A.out.hit_object) A.out.hit_object[ko] = first.object;
@@ -409,7 +409,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 template <int MODE>
-int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_tree_depth, LaunchArgs& A, uint32_t flags, void* stream) {
+int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_tree_depth, bool bounces, LaunchArgs& A, uint32_t flags, void* stream) {
     const bool trees = S.n_trees > 0;
     if (A.n <= 0) return RTAMD_OK;
     A.seg_len = 0;
@@ -454,6 +454,14 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_t
                 S.n_lights == 1 && !A.out.rgb && !A.out.rgb8 && !A.out.hit_object && !A.out.hit_prim && !A.out.hit_t &&
                 !A.out.n_rays;
 #endif
+    // whole frames, accumulators only, of kd scenes whose materials spawn no child rays under the plain
+    // tracer (Matte / Phong / Emissive: the reference's dragon and teapot scenes as shipped): a build of
+    // the kernel that leaves the bounce loop after one pass, like the area-light kernel
+    bool no_bounce = false;
+#ifndef RT_NO_STRAIGHT
+    no_bounce = MODE == MODE_TILES && !extended && trees && !area_only && !bounces && S.tracer_kind == RTAMD_TRACER_SHADE &&
+                !count && !executed && !A.out.rgb && !A.out.rgb8 && !A.out.hit_object && !A.out.hit_prim && !A.out.hit_t && !A.out.n_rays;
+#endif
 #ifdef RT_ONLY_HOT
     // experiment builds (tools/variant_bench.sh): only the whole-frame kernel of the benchmark scene
     if (area_only && !count && !executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
@@ -464,6 +472,7 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_t
     if (extended) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, true, true>), grid, block, 0, st, S, A);
     else if (area_only && !tiny_trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
     else if (area_only) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
+    else if (no_bounce) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, false, true, true>), grid, block, 0, st, S, A);
     else if (trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true>), grid, block, 0, st, S, A);
     else hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, false>), grid, block, 0, st, S, A);
 #else
@@ -477,6 +486,7 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_t
         else if (area_only && !tiny_trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
         else if (area_only) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
         else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, false, true>), grid, block, 0, st, S, A);
+        else if (no_bounce) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, false, true, true>), grid, block, 0, st, S, A);
         else hipLaunchKernelGGL((trace_kernel<MODE, 0, false, true>), grid, block, 0, st, S, A);
     } else {
         if (count) hipLaunchKernelGGL((trace_kernel<MODE, 1, false, false>), grid, block, 0, st, S, A);
@@ -498,6 +508,7 @@ struct rtamd_scene {
     int max_tree_depth;
     bool extended;                  // two-child or textured materials: the EXT kernels run
     bool two_child;                 // Transparent / Dielectric traced recursively
+    bool bounces;                   // some hit can spawn a child ray (mirror, glossy, two-child materials, path tracing)
     int tree_objects;               // objects of kind RTAMD_KDTREE (one tree may stand behind several)
 };
 
@@ -573,6 +584,7 @@ static int scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
     s->max_tree_depth = 0;
     s->extended = false;
     s->two_child = false;
+    s->bounces = d->tracer_kind == RTAMD_TRACER_PATH;
     s->tree_objects = 0;
     s->samplers_host = new (std::nothrow) rtamd_sampler[d->n_samplers];
     if (!s->samplers_host) { delete s; return fail(RTAMD_EINVAL, "out of host memory%s"); }
@@ -611,6 +623,7 @@ static int scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
             s->extended = true;
         }
         const bool two_children = m.kind == RTAMD_TRANSPARENT || m.kind == RTAMD_DIELECTRIC;
+        if (two_children || m.kind == RTAMD_REFLECTIVE || m.kind == RTAMD_GLOSSY_REFLECTIVE) s->bounces = true;
         if (two_children && d->tracer_kind != RTAMD_TRACER_AREA) {
             // Dielectric.shade hands trace_ray a third argument (material.py:459); only
             // WhittedTracer accepts it (tracer.py:43)
@@ -752,7 +765,7 @@ int rtamd_render_pixels(rtamd_scene* scene, const rtamd_camera* camera, uint64_t
     A.b3 = lens_points;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_PIXELS>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, A, flags, stream);
+    return launch<MODE_PIXELS>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, scene->bounces, A, flags, stream);
 }
 
 int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t* pixel_index,
@@ -777,7 +790,7 @@ int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t
     A.depth0 = depth;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_RAYS>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, A, flags, stream);
+    return launch<MODE_RAYS>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, scene->bounces, A, flags, stream);
 }
 
 int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t seed, int64_t n_tiles,
@@ -811,7 +824,7 @@ int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t 
     A.sum_rgb8 = sum_rgb8;
     A.sum_sq = sum_sq;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_TILES>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, A, flags, stream);
+    return launch<MODE_TILES>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, scene->bounces, A, flags, stream);
 }
 
 }  // extern "C"

@@ -645,6 +645,38 @@ def test_refilled_waves_render_the_same_frame(torch_gpu, scene, sample_dim):
     assert torch.equal(part.sum_rgb8.reshape(len(some), 64, 3), want)
 
 
+@pytest.mark.parametrize("scene", ("j", "k", "features_mesh", "mirror"))
+def test_accumulator_only_frames_of_kd_scenes(torch_gpu, scene):
+    """Whole frames of kd scenes with accumulators only go to kernel builds of their own where the
+    scene allows (materials that spawn no child ray under the plain tracer: `j`, `k`; `mirror` has a
+    mirror floor and stays with the general kernel): they must render what the general kernel
+    reports sample by sample."""
+    from raytracer_amd import flatten, runtime
+    torch = torch_gpu
+    world = common.world_for(scene)
+    ds = runtime.device_scene(world)
+    cam = flatten.camera_record(world)
+    tx, ty = runtime.tile_grid(cam.width, cam.height)
+    tiles = numpy.arange(tx * ty, dtype=numpy.int32)[::7].copy()
+    ns = len(world.viewplane.sampler.patterns[0])
+    ds.read_counters(reset=True)
+    fb = runtime.FrameBuffers(ds, tiles)
+    ds.render_tiles(cam, world.seed, fb.tile_ids, 0, ns, sum_rgb8=fb.sum_rgb8, sum_sq=fb.sum_sq)
+    torch.cuda.synchronize()
+    fast = ds.read_counters(reset=True)
+    per = ds.sample_buffers(len(tiles) * 64 * ns, want=("rgb", "rgb8"))
+    ref = runtime.FrameBuffers(ds, tiles)
+    ds.render_tiles(cam, world.seed, ref.tile_ids, 0, ns, sum_rgb8=ref.sum_rgb8, sum_sq=ref.sum_sq, per_sample=per)
+    torch.cuda.synchronize()
+    slow = ds.read_counters(reset=True)
+    assert fast == slow and fast["closest"] >= fast["samples"] > 0
+    assert torch.equal(fb.sum_rgb8, ref.sum_rgb8)
+    rgb8 = per[0]["rgb8"].reshape(len(tiles), ns, 64, 3).to(torch.int64).sum(dim=1).reshape(-1, 3)
+    assert torch.equal(fb.sum_rgb8, rgb8)
+    assert torch.allclose(fb.sum_sq, ref.sum_sq, rtol=1e-12, atol=1e-300)
+    assert int(fb.sum_rgb8.sum()) > 0
+
+
 def test_executed_work_counters_on_the_dragon(torch_gpu):
     """RTAMD_COUNT_EXECUTED runs the fast path and tallies it: same frame as the timed kernel, far
     fewer triangle tests than the reference's scan, and loads that add up."""

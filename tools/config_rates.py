@@ -27,6 +27,9 @@ CONFIGS = [
     ("j dragon 400x400 1spp (as shipped)", "j", None),
     ("cornellbox path traced 200x200 100spp (as shipped)", "cornellbox", None),
     ("mirror teapot on a mirror floor 500x500 1spp (as shipped)", "mirror", None),
+    # the reference's scene files at a frame size that fills the GPU: (width, height, sampler dimension)
+    ("J dragon of j.py at 1920x1080 4spp (Matte, point light)", "j", None, (1920, 1080, 2)),
+    ("K teapot of k.py at 1920x1080 4spp", "k", None, (1920, 1080, 2)),
 ]
 
 
@@ -36,11 +39,18 @@ def child(index, frames):
     import torch
     from raytracer_amd.world import World
     from raytracer_amd import flatten, runtime
-    label, scene, overrides = CONFIGS[index]
+    label, scene, overrides = CONFIGS[index][:3]
     world = World.__new__(World)
     if overrides:
         world.overrides = overrides
     World.__init__(world, viewmode="parallel", buildfunction=scene, seed=1)
+    if len(CONFIGS[index]) > 3:
+        import sampler
+        width, height, dim = CONFIGS[index][3]
+        world.viewplane.pixel_size *= world.viewplane.resolution[0] / float(width)      # same framing
+        world.viewplane.resolution = (width, height)
+        world.viewplane.sampler = sampler.MultiJitteredSampler(dim)
+        world.invalidate()
     ds = runtime.device_scene(world)
     cam = flatten.camera_record(world)
     tx, ty = runtime.tile_grid(cam.width, cam.height)
@@ -88,7 +98,7 @@ def main():
     if args.lib:
         env["RTAMD_LIB"] = os.environ["RTAMD_LIB"] = os.path.abspath(args.lib)
     rows = []
-    for i, (label, _, _) in enumerate(CONFIGS):
+    for i, (label, *_rest) in enumerate(CONFIGS):
         if args.only and not any(o in label for o in args.only):
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--child", str(i)]
