@@ -877,6 +877,23 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
             if (fast) { out_found = f2; out_t = b2.t; walking = false; }
         }
         if (!__ballot(walking)) { found = out_found; best.t = out_t; return; }
+#ifndef RT_NO_LIMITED_PREFILTER
+        // A ray that ends inside the tree's box (a light among the triangles: the reference's j.py)
+        // is answered by the first item in scan order that it hits, wherever on the ray that hit
+        // lies - the reference's walk, below.  But when no triangle at all is hit before the limit,
+        // that walk finds either nothing or a hit beyond the limit, and the ray is not occluded
+        // either way: the shadow tree, walked up to the limit, proves that faster, and only rays
+        // with some hit in there go on to the exact walk.
+        const bool limited = walking && !fast && origin_near_tree(T, r.o);
+        if (__ballot(limited)) {
+            bool f3 = false;
+            TriHit b3;
+            b3.t = 0;
+            shadow_tree_wave<COUNT>(S, T, limited, r, t_near, fmin(t_exit, limit * (1.0 + 1e-6) + 1e-6), false, stk, w, f3, b3);
+            if (limited && !f3) walking = false;
+            if (!__ballot(walking)) { found = out_found; best.t = out_t; return; }
+        }
+#endif
         steal_ok = false;
     }
 #endif
