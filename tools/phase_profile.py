@@ -18,6 +18,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tools"))
 LIB = os.path.join(REPO, "raytracer_amd", "csrc", "librtamd_phases.so")
 NAMES = ["descent", "pack16", "pack32", "big_plain", "big_boxes", "pop", "queries", "handover"]
 
@@ -36,6 +37,7 @@ def main():
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--workload", default="dragon_1080p_16spp_ao_arealight")
     ap.add_argument("--frames", type=int, default=2)
+    ap.add_argument("--config", type=int, default=-1, help="index into tools/config_rates.py CONFIGS instead of a bench workload")
     args = ap.parse_args()
     if args.build:
         build()
@@ -45,11 +47,24 @@ def main():
     import bench
     from raytracer_amd import capi, distributed, flatten, runtime
     from raytracer_amd.world import World
-    scene, overrides = bench.WORKLOADS[args.workload]
+    if args.config >= 0:
+        # a configuration of tools/config_rates.py (the reference's scene files at full HD among them)
+        import config_rates
+        entry = config_rates.CONFIGS[args.config]
+        args.workload, scene, overrides = entry[:3]
+    else:
+        scene, overrides = bench.WORKLOADS[args.workload]
     world = World.__new__(World)
     if overrides:
         world.overrides = overrides
     World.__init__(world, viewmode="parallel", buildfunction=scene, seed=1)
+    if args.config >= 0 and len(entry) > 3:
+        import sampler
+        width, height, dim = entry[3]
+        world.viewplane.pixel_size *= world.viewplane.resolution[0] / float(width)
+        world.viewplane.resolution = (width, height)
+        world.viewplane.sampler = sampler.MultiJitteredSampler(dim)
+        world.invalidate()
     job = distributed.FrameJob(world, 0, 1)
     lib = capi.library()
     table = (C.c_ulonglong * 48)()
