@@ -189,6 +189,53 @@ __device__ __forceinline__ int first_lane(unsigned long long mask) {
 // Here the same system is solved by Cramer's rule in the Moeller-Trumbore arrangement;
 // a singular system (the reference raises) is a miss because every comparison with
 // the resulting inf/NaN is false.
+#ifdef RT_TRI_LU
+// Checking builds only: the system solved the way numpy.linalg.solve does at geometry.py:440
+// (LAPACK dgesv: LU with partial pivoting, the pivot's reciprocal, a rank-1 update, the two
+// triangular solves), operation for operation like the CPU checker.  Cramer's rule (below) agrees
+// with it to rounding, which decides a test differently only where a ray grazes an edge to within
+// that rounding; this build tells such knife-edge differences from real ones.
+__device__ __forceinline__ bool tri_solve_v(V3 v0, V3 e1, V3 e2, const Ray& r,
+                                            double& alpha, double& beta, double& t) {
+    const V3 f = v0 - r.o;
+    double a0[4] = {e1.x, e2.x, -r.d.x, -f.x}, a1[4] = {e1.y, e2.y, -r.d.y, -f.y}, a2[4] = {e1.z, e2.z, -r.d.z, -f.z};
+    auto swap_rows = [](double* x, double* y) {
+        for (int k = 0; k < 4; ++k) { const double tmp = x[k]; x[k] = y[k]; y[k] = tmp; }
+    };
+    {
+        const double m0 = fabs(a0[0]), m1 = fabs(a1[0]), m2 = fabs(a2[0]);
+        if (m1 > m0 && !(m2 > m1)) swap_rows(a0, a1);
+        else if (m2 > m0 && m2 > m1) swap_rows(a0, a2);
+    }
+    if (a0[0] == 0.0) return false;
+    {
+        const double rcp = 1.0 / a0[0];
+        a1[0] *= rcp; a2[0] *= rcp;
+        a1[1] -= a1[0] * a0[1]; a1[2] -= a1[0] * a0[2];
+        a2[1] -= a2[0] * a0[1]; a2[2] -= a2[0] * a0[2];
+    }
+    if (fabs(a2[1]) > fabs(a1[1])) swap_rows(a1, a2);
+    if (a1[1] == 0.0) return false;
+    {
+        const double rcp = 1.0 / a1[1];
+        a2[1] *= rcp;
+        a2[2] -= a2[1] * a1[2];
+    }
+    if (a2[2] == 0.0) return false;
+    double b0 = a0[3], b1 = a1[3], b2 = a2[3];
+    b1 -= b0 * a1[0];
+    b2 -= b0 * a2[0];
+    b2 -= b1 * a2[1];
+    b2 = b2 / a2[2];
+    b0 -= b2 * a0[2];
+    b1 -= b2 * a1[2];
+    b1 = b1 / a1[1];
+    b0 -= b1 * a0[1];
+    b0 = b0 / a0[0];
+    alpha = b0; beta = b1; t = b2;
+    return alpha > EPS && beta > EPS && t > EPS && alpha + beta < 1.0;
+}
+#else
 __device__ __forceinline__ bool tri_solve_v(V3 v0, V3 e1, V3 e2, const Ray& r,
                                             double& alpha, double& beta, double& t) {
 #ifdef RT_TRI_FMA
@@ -212,6 +259,7 @@ __device__ __forceinline__ bool tri_solve_v(V3 v0, V3 e1, V3 e2, const Ray& r,
     t = dot(e2, qvec) * inv;
     return alpha > EPS && beta > EPS && t > EPS && alpha + beta < 1.0;
 }
+#endif
 // bare triangle given as 9 contiguous doubles v0, e1, e2
 __device__ __forceinline__ bool tri_solve(const double* g, const Ray& r, double& alpha, double& beta, double& t) {
     return tri_solve_v(ld3(g), ld3(g + 3), ld3(g + 6), r, alpha, beta, t);

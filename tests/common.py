@@ -65,7 +65,8 @@ def rgb_close(a, b, rtol=RGB_RTOL, atol=RGB_ATOL):
     with numpy.errstate(invalid="ignore", divide="ignore"):
         err = numpy.abs(a - b)
         rel = numpy.where(same, 0.0, err / numpy.maximum(numpy.abs(b), atol / rtol))
-    ok = same | (err <= atol + rtol * numpy.abs(b))
+    # (an infinite value only equals the same infinity: inf <= rtol * inf must not pass for a finite partner)
+    ok = same | (numpy.isfinite(a) & numpy.isfinite(b) & (err <= atol + rtol * numpy.abs(b)))
     return bool(ok.all()), float(numpy.nanmax(rel)) if rel.size else 0.0
 
 

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""One-off sweep over more worlds of the random families than the test suite renders:
+  python tests/fuzz_sweep.py FIRST LAST [MESH_FIRST MESH_LAST]
+Every world goes through tests/test_gpu_parity.check_tiles_against_oracle (whole frames, every sample, ids /
+ray counts / reference work exact, the timed and both counting kernels the same frame).  Needs a GPU."""
+import os
+import sys
+import traceback
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def main():
+    import torch
+    import __graft_entry__  # noqa: F401  (puts the package on the path)
+    from raytracer_amd.world import World
+    from raytracer_amd import flatten
+    World(viewmode="parallel", buildfunction="fuzz_0", seed=1)       # loads the scene files
+    import test_gpu_parity as t
+    fuzz = [m for name, m in sys.modules.items() if name.startswith("rtamd_scene_fuzz")][0]
+    a = [int(x) for x in sys.argv[1:]]
+    jobs = [("fuzz_%d", fuzz._make, k) for k in range(a[0], a[1])]
+    if len(a) > 2:
+        jobs += [("fuzzmesh_%d", fuzz._make_mesh, k) for k in range(a[2], a[3])]
+    bad = 0
+    for pattern, make, k in jobs:
+        name = pattern % k
+        if k >= (fuzz.N_WORLDS if make is fuzz._make else fuzz.N_MESH_WORLDS):
+            make(k)
+        try:
+            world = World(viewmode="parallel", buildfunction=name, seed=1)
+            t.check_tiles_against_oracle(torch, world, flatten.flatten_world(world), 96, None, name)
+        except Exception:
+            bad += 1
+            print("FAILED %s" % name, flush=True)
+            traceback.print_exc()
+    print("%d worlds, %d failed" % (len(jobs), bad), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
