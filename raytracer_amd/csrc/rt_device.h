@@ -1786,10 +1786,17 @@ __device__ __forceinline__ V3 hemisphere_about(V3 w, V3 sp) {
 // without a kd-tree therefore call it as a function (mirror hall 4K frame: 125 -> 106 ms,
 // foursphere 0.18 -> 0.14 ms); in the kd kernels the call's own register conventions cost more
 // than they save (dragon frame 11.46 -> 11.73 ms), so those inline it.
+#ifdef RT_POW_ALT
+// checking builds only: another evaluation of the same power (a few ulps off), to tell differences
+// against the CPU checker that hang on the last bit of pow from any others
+__device__ __attribute__((noinline)) double pow_as_call(double a, double b) { return a > 0.0 ? exp2(b * log2(a)) : pow(a, b); }
+template <bool CALL> __device__ __forceinline__ double rt_pow(double a, double b) { return pow_as_call(a, b); }
+#else
 __device__ __attribute__((noinline)) double pow_as_call(double a, double b) { return pow(a, b); }
 template <bool CALL> __device__ __forceinline__ double rt_pow(double a, double b) {
     return CALL ? pow_as_call(a, b) : pow(a, b);
 }
+#endif
 
 // GlossySpecular.f (material.py:88-97) with ks*cs folded into `spec`.
 template <bool POW_CALL>
