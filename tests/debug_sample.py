@@ -78,20 +78,3 @@ print("objects:", [(o.kind, o.has_transform, o.n_inner, o.tree, o.smooth) for o 
 mats = flatten.flatten_world(world).arrays["materials"]
 mrec = (capi.Material * (len(mats) // C.sizeof(capi.Material))).from_buffer(bytearray(mats))
 print("material kinds:", [m.kind for m in mrec])
-# with every glossy lobe switched off (kr = 0): what remains is the local shading
-import material as _material
-seen = set()
-for ob in world.objects:
-    stack = [ob]
-    while stack:
-        o = stack.pop()
-        for attr in ("material", "alt_material"):
-            m = getattr(o, attr, None)
-            if m is not None and id(m) not in seen and hasattr(m, "reflective_bdrf"):
-                seen.add(id(m))
-                m.reflective_bdrf.ks = 0.0
-        for attr in ("shape", "obj", "object", "mesh"):
-            if hasattr(o, attr):
-                stack.append(getattr(o, attr))
-world.lights = lights
-both("reflective kr = 0 (objects' own materials)")
