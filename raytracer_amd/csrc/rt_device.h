@@ -352,6 +352,8 @@ struct KdStack {
     int32_t* slot;      // LDS, [64]: lane ids by rank while walks are handed over (see kd_query_wave)
     bool tiny_ok;       // trees of a few levels may be scanned by single lanes throughout (a constant
                         // false in the kernel that is only launched for deep trees drops that code)
+    bool prefilter_ok;  // shadow rays that end inside a tree's box may ask the shadow tree first (a
+                        // constant false keeps that second copy of the walk out of a kernel)
 };
 #define RT_KD_STACK_LDS_BYTES (LDS_STACK * 64 * 12)
 #ifndef RT_SMALL_LEAF
@@ -932,7 +934,7 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
         // that walk finds either nothing or a hit beyond the limit, and the ray is not occluded
         // either way: the shadow tree, walked up to the limit, proves that faster, and only rays
         // with some hit in there go on to the exact walk.
-        const bool limited = walking && !fast && origin_near_tree(T, r.o);
+        const bool limited = stk.prefilter_ok && walking && !fast && origin_near_tree(T, r.o);
         if (__ballot(limited)) {
             bool f3 = false;
             TriHit b3;

@@ -222,6 +222,8 @@ __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC
         stk.t = stack_t;
         stk.slot = stack_slot;
         stk.tiny_ok = TINY_OK;
+        // (the benchmark's kernel keeps to the code its frame runs: its lights lie outside the tree's box)
+        stk.prefilter_ok = !(AREA_ONLY && !TINY_OK);
         NoFeed no_feed;
         const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY, NoFeed, NO_BOUNCE>(S, stk, live, ray, A.depth0, dr, work, first, no_feed);
         if (live) {
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES_ANALYTIC) void refill_kernel(co
     KdStack stk;
     stk.node = nullptr; stk.t = nullptr; stk.slot = nullptr;     // no kd-tree, no traversal stack
     stk.tiny_ok = false;
+    stk.prefilter_ok = false;
     trace_wave<COUNT, false, false, false, TileFeed>(S, stk, live, ray, A.depth0, dr, work, first, feed);
     __syncthreads();
     // lane l adds the sums of pixel l of the wave's tile (zero where the wave traced nothing)
