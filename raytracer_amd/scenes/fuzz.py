@@ -18,7 +18,7 @@ from mesh_parser import read_mesh
 from sampler import MultiJitteredSampler, RegularSampler
 from tracer import AreaLightTracer, Tracer, ViewPlane, WhittedTracer
 
-N_WORLDS = 48
+N_WORLDS = 128
 
 
 def _vec(r, lo, hi):
@@ -190,7 +190,7 @@ WORLDS = [_make(k) for k in range(N_WORLDS)]
 
 
 # ---- `fuzzmesh_<k>`: the teapot (6 320 triangles, a tree big enough for a shadow tree) in random company
-N_MESH_WORLDS = 12
+N_MESH_WORLDS = 40
 
 
 def build_mesh_world(world, viewmode, k):

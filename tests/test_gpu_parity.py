@@ -53,10 +53,11 @@ def test_gpu_tiles_match_oracle(torch_gpu, scene, tiles, samples):
     check_tiles_against_oracle(torch_gpu, common.world_for(scene), common.flat_for(scene), tiles, samples, scene)
 
 
-@pytest.mark.parametrize("first", range(9, 45, 6))
+@pytest.mark.parametrize("first", range(9, 123, 6))
 def test_random_worlds_match_oracle(torch_gpu, first):
     """Six more seeded random worlds per case (raytracer_amd/scenes/fuzz.py), whole frames, every
-    sample, against the oracle (which the reference pins on the first nine of the family)."""
+    sample, against the oracle (which the reference pins on the first nine of the family).  (A sweep
+    over thousands more, tests/fuzz_sweep.py, is run by hand.)"""
     from raytracer_amd import flatten
     from raytracer_amd.world import World
     for k in range(first, first + 6):
@@ -64,9 +65,9 @@ def test_random_worlds_match_oracle(torch_gpu, first):
         check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), 96, None, "fuzz_%d" % k)
 
 
-@pytest.mark.parametrize("first", range(0, 12, 4))
+@pytest.mark.parametrize("first", range(0, 40, 4))
 def test_random_teapot_worlds_match_oracle(torch_gpu, first):
-    """Twelve seeded worlds around the teapot's kd-tree (`fuzzmesh_<k>`, raytracer_amd/scenes/fuzz.py):
+    """Forty seeded worlds around the teapot's kd-tree (`fuzzmesh_<k>`, raytracer_amd/scenes/fuzz.py):
     a mesh with a shadow tree under every tracer, bare and instanced, smooth and flat, with
     triangles that cast no shadow, lights inside and outside its box.  Whole frames, every sample."""
     from raytracer_amd import flatten
