@@ -571,13 +571,21 @@ __device__ __forceinline__ void boxed_leaf_closest_lane(const rtamd_scene_desc& 
     }
 }
 
-// The single-precision walk of a shadow tree (below) is only as exact as the ray's origin is in
-// single precision: an origin whose coordinates are much larger than the tree's own would move
-// the walk by more than the slack the tree was built with.  Such rays take the exact walk.
-__device__ __forceinline__ bool origin_near_tree(const rtamd_tree& T, V3 o) {
-    const double reach = fmax(fmax(fmax(fabs(T.bbox_lo[0]), fabs(T.bbox_hi[0])), fmax(fabs(T.bbox_lo[1]), fabs(T.bbox_hi[1]))),
-                              fmax(fabs(T.bbox_lo[2]), fabs(T.bbox_hi[2])));
-    return fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)) <= 16.0 * reach;
+// The single-precision walk of a shadow tree (below) is only as exact as the point it starts from is in
+// single precision: coordinates much larger than the tree's own would move the walk by more than
+// the slack the tree was built with.  A ray whose origin lies farther than 16 times the tree's
+// largest coordinate from the coordinate origin therefore starts its walk from a point moved along
+// the ray to within about that largest coordinate of the tree's box (walk_shift: the distance, as
+// a float; 0 for other rays); the triangle tests keep the ray as it is.
+__device__ __forceinline__ double tree_reach(const rtamd_tree& T) {
+    return fmax(fmax(fmax(fabs(T.bbox_lo[0]), fabs(T.bbox_hi[0])), fmax(fabs(T.bbox_lo[1]), fabs(T.bbox_hi[1]))),
+                fmax(fabs(T.bbox_lo[2]), fabs(T.bbox_hi[2])));
+}
+__device__ __forceinline__ float walk_shift(const rtamd_tree& T, const Ray& q, double near) {
+    const double reach = tree_reach(T);
+    if (fmax(fmax(fabs(q.o.x), fabs(q.o.y)), fabs(q.o.z)) <= 16.0 * reach) return 0.0f;
+    const double dmax = fmax(fmax(fabs(q.d.x), fabs(q.d.y)), fabs(q.d.z));
+    return (float)fmax(0.0, near - reach / dmax);
 }
 
 // Shadow queries that any hit decides, on a tree's shadow tree (rtamd_tree::shadow_root).
@@ -590,7 +598,7 @@ __device__ __forceinline__ bool origin_near_tree(const rtamd_tree& T, V3 o) {
 // registers and the instructions of a step.  What makes that safe is in the tree, not here: the
 // host lists a triangle in every leaf whose cell its box reaches into after widening the box
 // by far more (4e-5 of the tree's largest coordinate) than the walk's rounding can move a point
-// (about 4e-6 of it for an origin within 16 times that coordinate, see origin_near_tree), and
+// (about 4e-6 of it for a starting point within 16 times that coordinate, see walk_shift), and
 // widens the leaf boxes by the same amount.  The triangle tests are
 // the exact double-precision ones.
 //
@@ -611,10 +619,23 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     const int lane = lane_id();
     Ray r = ray_in;                         // own ray, or the one whose walk this lane took over
-    float ox = (float)r.o.x, oy = (float)r.o.y, oz = (float)r.o.z;
+    // the walk's own parameter starts `shift` along the ray (walk_shift): its origin, and every distance
+    // it keeps, are taken from there
+    float shift = walking ? walk_shift(T, r, near_in) : 0.0f;
+    float ox, oy, oz;
+    auto walk_origin = [&]() {
+        ox = (float)r.o.x; oy = (float)r.o.y; oz = (float)r.o.z;
+        if (shift != 0.0f) {
+            ox = (float)(r.o.x + (double)shift * r.d.x); oy = (float)(r.o.y + (double)shift * r.d.y); oz = (float)(r.o.z + (double)shift * r.d.z);
+        }
+    };
+    walk_origin();
     auto reciprocal = [](double d) { return fminf(fmaxf(__builtin_amdgcn_rcpf((float)d), -3.0e37f), 3.0e37f); };
     float ix = reciprocal(r.d.x), iy = reciprocal(r.d.y), iz = reciprocal(r.d.z);
-    float t_near = (float)near_in, t_far = (float)exit_in, t_exit = (float)exit_in;
+    float t_near = (float)(near_in - (double)shift), t_far = (float)(exit_in - (double)shift), t_exit = t_far;
+    // the same for the lane's second ray
+    const float shift2 = (TWO && pending2) ? walk_shift(T, *ray2, near2) : 0.0f;
+    const float near2w = TWO ? (float)(near2 - (double)shift2) : 0.0f, exit2w = TWO ? (float)(exit2 - (double)shift2) : 0.0f;
     u32x2* lds = reinterpret_cast<u32x2*>(stk.t);                   // [LDS_STACK][64] entries
     u32x2 deep[STACK_MAX - LDS_STACK];
     int sp = 0, sb = 0, owner = lane;
@@ -640,10 +661,11 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
             // this lane's part of its first ray's walk is done: on to its second ray
             pending2 = false;
             r = *ray2;
-            ox = (float)r.o.x; oy = (float)r.o.y; oz = (float)r.o.z;
+            shift = shift2;
+            walk_origin();
             ix = reciprocal(r.d.x); iy = reciprocal(r.d.y); iz = reciprocal(r.d.z);
             node = T.shadow_root;
-            t_near = (float)near2; t_far = t_exit = (float)exit2;
+            t_near = near2w; t_far = t_exit = exit2w;
             sp = 0; sb = 0; owner = lane + 64;
             found = false; walking = true;
         }
@@ -664,11 +686,12 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
                 __syncthreads();
                 const V3 no = v3(__shfl(ray2->o.x, src), __shfl(ray2->o.y, src), __shfl(ray2->o.z, src));
                 const V3 nd = v3(__shfl(ray2->d.x, src), __shfl(ray2->d.y, src), __shfl(ray2->d.z, src));
-                const float n_near = __shfl((float)near2, src), n_exit = __shfl((float)exit2, src);
+                const float n_near = __shfl(near2w, src), n_exit = __shfl(exit2w, src), n_shift = __shfl(shift2, src);
                 if (gives) pending2 = false;
                 if (takes) {
                     r.o = no; r.d = nd; owner = src + 64;
-                    ox = (float)no.x; oy = (float)no.y; oz = (float)no.z;
+                    shift = n_shift;
+                    walk_origin();
                     ix = reciprocal(nd.x); iy = reciprocal(nd.y); iz = reciprocal(nd.z);
                     node = T.shadow_root; t_near = n_near; t_far = n_exit; t_exit = n_exit;
                     sp = 0; sb = 0;
@@ -706,9 +729,11 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
                 const int n_owner = __shfl(owner, src);
                 const int32_t n_node = __shfl((int)g.x, src);
                 const float n_t = __uint_as_float((unsigned)__shfl((int)g.y, src)), n_exit = __shfl(g_exit, src);
+                const float n_shift = __shfl(shift, src);
                 if (takes) {
                     r.o = no; r.d = nd; owner = n_owner;
-                    ox = (float)no.x; oy = (float)no.y; oz = (float)no.z;
+                    shift = n_shift;
+                    walk_origin();
                     ix = reciprocal(nd.x); iy = reciprocal(nd.y); iz = reciprocal(nd.z);
                     node = n_node; t_near = n_t; t_far = n_exit; t_exit = n_exit;
                     sp = 0; sb = 0;
@@ -918,7 +943,7 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
     // it walks the tree's shadow tree (the same triangles in a kd-tree built for this walk);
     // only rays with a limit inside the tree's box go on below, on the reference's tree
     if (STEAL && S.leaf_aabb != nullptr && T.shadow_root > 0) {
-        const bool fast = steal_ok && origin_near_tree(T, r.o);
+        const bool fast = steal_ok;
         if (__ballot(fast)) {
             bool f2 = false;
             TriHit b2;
@@ -934,7 +959,7 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
         // that walk finds either nothing or a hit beyond the limit, and the ray is not occluded
         // either way: the shadow tree, walked up to the limit, proves that faster, and only rays
         // with some hit in there go on to the exact walk.
-        const bool limited = stk.prefilter_ok && walking && !fast && origin_near_tree(T, r.o);
+        const bool limited = stk.prefilter_ok && walking && !fast;
         if (__ballot(limited)) {
             bool f3 = false;
             TriHit b3;
@@ -1925,8 +1950,7 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
             const bool in1 = casts && lit && root_box(T, q1, near1, exit1);
             const bool in2 = casts && facing && root_box(T, q2, near2, exit2);
             const bool free2 = !bounded || (exit2 * (1.0 + 1e-9) + 1e-9 < limit);
-            const bool near = origin_near_tree(T, q1.o);          // both rays start at the hit point
-            if (!__ballot((in2 && !free2) || ((in1 || in2) && !near))) {
+            if (!__ballot(in2 && !free2)) {
                 w.mark(34);
                 // light.in_shadow for both rays: the analytic objects first, the tree last
                 if (lit) w.shadow++;
