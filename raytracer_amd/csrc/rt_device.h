@@ -352,6 +352,9 @@ struct KdStack {
     int32_t* slot;      // LDS, [64]: lane ids by rank while walks are handed over (see kd_query_wave)
     bool tiny_ok;       // trees of a few levels may be scanned by single lanes throughout (a constant
                         // false in the kernel that is only launched for deep trees drops that code)
+    bool fused_always;  // whole-frame area-light kernel: the host has shown that every wave takes the path
+                        // that traces both shadow rays of a hit in one shadow-tree query (direct_light_wave);
+                        // a constant true leaves the general path out of the kernel
     bool prefilter_ok;  // shadow rays that end inside a tree's box may ask the shadow tree first (a
                         // constant false keeps that second copy of the walk out of a kernel)
 };
@@ -1873,8 +1876,8 @@ template <int COUNT, bool EXT, bool TREES, bool ONE_TREE = false>
 __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, bool lit, const rtamd_material& m,
                                 const Hit& h, V3 wo, bool area, V3 tex, Draw& dr, Work<COUNT>& w) {
 #ifndef RT_NO_FUSED_SHADOWS
-    if (ONE_TREE && COUNT != 1 && !EXT && S.ambient.kind == RTAMD_AMBIENT_OCCLUDER && S.lights[0].cast_shadow &&
-        S.leaf_aabb != nullptr) {
+    if (ONE_TREE && COUNT != 1 && !EXT && (stk.fused_always || (S.ambient.kind == RTAMD_AMBIENT_OCCLUDER && S.lights[0].cast_shadow &&
+                                                               S.leaf_aabb != nullptr))) {
         // One kd-tree, an ambient occluder and one shadow-casting light: the occlusion ray and
         // the light's shadow ray of a hit are both known before either is traced (no draw
         // happens inside a query), and which is traced first changes neither answer.  When the
@@ -1883,7 +1886,7 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
         for (int i = 0; i < S.n_objects; ++i) if (S.objects[i].kind == RTAMD_KDTREE) tree_object = i;
         const rtamd_object& tob = S.objects[tree_object];
         const rtamd_tree& T = S.trees[tob.tree];
-        if (T.shadow_root > 0) {
+        if (stk.fused_always || T.shadow_root > 0) {
             const rtamd_light& lt = S.lights[0];
             const Draw drawn = dr;          // if the wave cannot take this path the draws are made again below
             // ambient_color.L(sr), AmbientOccluder (light.py:85-100)
@@ -1950,7 +1953,9 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
             const bool in1 = casts && lit && root_box(T, q1, near1, exit1);
             const bool in2 = casts && facing && root_box(T, q2, near2, exit2);
             const bool free2 = !bounded || (exit2 * (1.0 + 1e-9) + 1e-9 < limit);
-            if (!__ballot(in2 && !free2)) {
+            // (fused_always: the emitter lies outside the tree's box by a margin, so every light ray
+            // leaves the box before it reaches the light, whatever rounding does to the two distances)
+            if (stk.fused_always || !__ballot(in2 && !free2)) {
                 w.mark(34);
                 // light.in_shadow for both rays: the analytic objects first, the tree last
                 if (lit) w.shadow++;

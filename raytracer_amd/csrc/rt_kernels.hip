@@ -163,7 +163,8 @@ __device__ __forceinline__ bool tile_ray(const rtamd_scene_desc& S, const Launch
 // do not pay for.
 // TREES = false instantiations serve scenes without a kd-tree (analytic primitives only):
 // no traversal code, no LDS stack, and the registers go to the shading loop.
-template <int MODE, int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, bool TINY_OK = true, bool NO_BOUNCE = false>
+template <int MODE, int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, bool TINY_OK = true, bool NO_BOUNCE = false,
+          bool FUSED = false>
 __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
     // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC
         stk.tiny_ok = TINY_OK;
         // (the benchmark's kernel keeps to the code its frame runs: its lights lie outside the tree's box)
         stk.prefilter_ok = !(AREA_ONLY && !TINY_OK);
+        stk.fused_always = FUSED;
         NoFeed no_feed;
         const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY, NoFeed, NO_BOUNCE>(S, stk, live, ray, A.depth0, dr, work, first, no_feed);
         if (live) {
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES_ANALYTIC) void refill_kernel(co
     KdStack stk;
     stk.node = nullptr; stk.t = nullptr; stk.slot = nullptr;     // no kd-tree, no traversal stack
     stk.tiny_ok = false;
+    stk.fused_always = false;
     stk.prefilter_ok = false;
     trace_wave<COUNT, false, false, false, TileFeed>(S, stk, live, ray, A.depth0, dr, work, first, feed);
     __syncthreads();
@@ -412,7 +415,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 template <int MODE>
-int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_tree_depth, bool bounces, LaunchArgs& A, uint32_t flags, void* stream) {
+int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_tree_depth, bool bounces, bool fused_always, LaunchArgs& A, uint32_t flags, void* stream) {
     const bool trees = S.n_trees > 0;
     if (A.n <= 0) return RTAMD_OK;
     A.seg_len = 0;
@@ -467,12 +470,14 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_t
 #endif
 #ifdef RT_ONLY_HOT
     // experiment builds (tools/variant_bench.sh): only the whole-frame kernel of the benchmark scene
-    if (area_only && !count && !executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
+    if (area_only && !count && !executed && fused_always) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false, false, true>), grid, block, 0, st, S, A);
+    else if (area_only && !count && !executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
     else return fail(RTAMD_EUNSUPPORTED, "this build holds the whole-frame area-light kernel only%s");
 #elif defined(RT_ONLY_TILES)
     // experiment builds: the uncounted whole-frame kernels only
     if (MODE != MODE_TILES || count || executed) return fail(RTAMD_EUNSUPPORTED, "this build holds the uncounted tile kernels only%s");
     if (extended) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, true, true>), grid, block, 0, st, S, A);
+    else if (area_only && !tiny_trees && fused_always) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false, false, true>), grid, block, 0, st, S, A);
     else if (area_only && !tiny_trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
     else if (area_only) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
     else if (no_bounce) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, false, true, true>), grid, block, 0, st, S, A);
@@ -486,6 +491,7 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_t
     } else if (trees) {
         if (count) hipLaunchKernelGGL((trace_kernel<MODE, 1, false, true>), grid, block, 0, st, S, A);
         else if (area_only && executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 2, false, true, true>), grid, block, 0, st, S, A);
+        else if (area_only && !tiny_trees && fused_always) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false, false, true>), grid, block, 0, st, S, A);
         else if (area_only && !tiny_trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
         else if (area_only) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
         else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, false, true>), grid, block, 0, st, S, A);
@@ -512,6 +518,7 @@ struct rtamd_scene {
     bool extended;                  // two-child or textured materials: the EXT kernels run
     bool two_child;                 // Transparent / Dielectric traced recursively
     bool bounces;                   // some hit can spawn a child ray (mirror, glossy, two-child materials, path tracing)
+    bool fused_always;              // see KdStack::fused_always: shown here, on the host copies of the tables
     int tree_objects;               // objects of kind RTAMD_KDTREE (one tree may stand behind several)
 };
 
@@ -718,6 +725,28 @@ static int scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
         if (t.shadow_root < 0 || t.shadow_root >= d->n_kd_nodes) { rtamd_scene_destroy(s); return fail(RTAMD_EINVAL, "shadow tree root outside kd_nodes%s"); }
         if (t.depth > s->max_tree_depth) s->max_tree_depth = t.depth;
     }
+    // Whether every wave of a whole-frame launch can trace both shadow rays of a hit in one shadow-tree
+    // query (direct_light_wave): one untransformed tree with a shadow tree, an ambient occluder, and one
+    // shadow-casting area light whose emitter - corner + [0,1] edge_u + [0,1] edge_v - is separated from the
+    // tree's box along some axis by a hundredth of the scene's size: then every light ray leaves the box
+    // before its limit, and a ray's every possible hit lies before the light.
+    s->fused_always = false;
+    if (d->tracer_kind == RTAMD_TRACER_AREA && !s->extended && s->tree_objects == 1 && d->n_lights == 1 &&
+        d->ambient.kind == RTAMD_AMBIENT_OCCLUDER && d->leaf_aabb && lights[0].kind == RTAMD_AREA && lights[0].cast_shadow) {
+        const rtamd_object* tob = nullptr;
+        for (int i = 0; i < d->n_objects; ++i) if (objects[i].kind == RTAMD_KDTREE) tob = &objects[i];
+        if (tob && !tob->has_transform && trees[tob->tree].shadow_root > 0) {
+            const rtamd_tree& t = trees[tob->tree];
+            const rtamd_light& l = lights[0];
+            double size = 0;
+            for (int k = 0; k < 3; ++k) size = fmax(size, fmax(fmax(fabs(t.bbox_lo[k]), fabs(t.bbox_hi[k])), fabs(l.position[k]) + fabs(l.edge_u[k]) + fabs(l.edge_v[k])));
+            for (int k = 0; k < 3; ++k) {
+                const double lo = l.position[k] + fmin(0.0, l.edge_u[k]) + fmin(0.0, l.edge_v[k]);
+                const double hi = l.position[k] + fmax(0.0, l.edge_u[k]) + fmax(0.0, l.edge_v[k]);
+                if (lo > t.bbox_hi[k] + 0.01 * size || hi < t.bbox_lo[k] - 0.01 * size) s->fused_always = true;
+            }
+        }
+    }
     *out = s;
     return RTAMD_OK;
 }
@@ -768,7 +797,7 @@ int rtamd_render_pixels(rtamd_scene* scene, const rtamd_camera* camera, uint64_t
     A.b3 = lens_points;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_PIXELS>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, scene->bounces, A, flags, stream);
+    return launch<MODE_PIXELS>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, scene->bounces, scene->fused_always, A, flags, stream);
 }
 
 int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t* pixel_index,
@@ -793,7 +822,7 @@ int rtamd_trace_rays(rtamd_scene* scene, uint64_t seed, int64_t n, const int32_t
     A.depth0 = depth;
     A.out = *out;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_RAYS>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, scene->bounces, A, flags, stream);
+    return launch<MODE_RAYS>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, scene->bounces, scene->fused_always, A, flags, stream);
 }
 
 int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t seed, int64_t n_tiles,
@@ -827,7 +856,7 @@ int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t 
     A.sum_rgb8 = sum_rgb8;
     A.sum_sq = sum_sq;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
-    return launch<MODE_TILES>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, scene->bounces, A, flags, stream);
+    return launch<MODE_TILES>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, scene->bounces, scene->fused_always, A, flags, stream);
 }
 
 }  // extern "C"

@@ -711,12 +711,14 @@ def test_executed_work_counters_on_the_dragon(torch_gpu):
         ds.render_tiles(cam, world.seed, fb.tile_ids, 0, 16, sum_rgb8=fb.sum_rgb8, count_executed=True, count_work=True)
 
 
-@pytest.mark.parametrize("case", ("panel_inside_the_box", "phong_dragon", "teapot_smooth", "tiny_instance"))
+@pytest.mark.parametrize("case", ("panel_inside_the_box", "panel_beside_the_box", "panel_far_from_the_box", "phong_dragon",
+                                  "teapot_smooth", "tiny_instance"))
 def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
     """One kd-tree, an ambient occluder, one light, AreaLightTracer: the whole-frame kernel traces
     both shadow rays of a hit in one query on the mesh's shadow tree - unless some light ray
-    ends inside the mesh's box, which sends the wave down the general path.  Both ways, a glossy
-    material and a smooth mesh: timed = executed-work = reference-work kernel = oracle."""
+    ends inside the mesh's box, which sends the wave down the general path.  Both ways, an emitter
+    just outside and well outside the box, a glossy material and a smooth mesh: timed =
+    executed-work = reference-work kernel = oracle."""
     import numpy as np
     import raytracer_amd
     raytracer_amd.activate()
@@ -751,6 +753,14 @@ def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
         if case == "panel_inside_the_box":
             # the emitter hangs between the dragon's coils: light rays end inside the tree's box
             panel = Rectangle(np.array((-3., 4., 1.)), 3, 2, np.array((0., 0., -1.)), np.array((1., 0., 0.)),
+                              Emissive(30., np.array((1., .96, .9))), sampler)
+            world.lights = [AreaLight(panel.material, panel, 6.)]
+        elif case in ("panel_beside_the_box", "panel_far_from_the_box"):
+            # an emitter outside the tree's box (z up to 3.15): far enough and the library drops the
+            # general path from the kernel it launches (it shows on the host that every light ray leaves
+            # the box before it ends); a hair outside and it must keep it
+            z = 3.2 if case == "panel_beside_the_box" else 6.0
+            panel = Rectangle(np.array((-3., 4., z)), 3, 2, np.array((0., 0., -1.)), np.array((1., 0., 0.)),
                               Emissive(30., np.array((1., .96, .9))), sampler)
             world.lights = [AreaLight(panel.material, panel, 6.)]
         else:
