@@ -728,8 +728,8 @@ def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
     from raytracer_amd import flatten
     if case == "tiny_instance":
         # the teapot at a fiftieth of its size: in its own space the shadow rays of the ground
-        # start hundreds of teapots away, too far for the single-precision walk, which must
-        # leave them to the exact one
+        # start hundreds of teapots away, too far for a single-precision walk from their origin:
+        # it starts from a point moved along the ray to just outside the tree's box
         import affinetransform as transform
         from geometry import Instance
         from raytracer_amd.world import World
