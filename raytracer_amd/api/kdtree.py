@@ -122,8 +122,16 @@ class KDTree(GeometryObject):
         self.built_on = "host"
         if not leaf and self._wants_device(len(bounding_boxes.boxes)) and \
                 [float(v) for v in min_d] == [bb.x0, bb.y0, bb.z0] and [float(v) for v in max_d] == [bb.x1, bb.y1, bb.z1]:
-            self._build_on_device()
-            return
+            try:
+                self._build_on_device()
+                return
+            except RuntimeError as e:
+                # RTAMD_KD_BUILD=auto: the device build is an accelerator for the host build below, which
+                # yields the same arrays; an explicit RTAMD_KD_BUILD=device fails loudly
+                if KD_BUILD == "device":
+                    raise
+                import warnings
+                warnings.warn("device kd build not available (%s): building on the host" % e)
         self._axis, self._split = [], []
         self._left, self._right = [], []
         self._first, self._count = [], []
