@@ -54,6 +54,10 @@ PLAN = {
     "mirror":           ("parallel", None, 2500),
     "mirroralt":        ("parallel", None, 2500),
     "dragon_area":      ("parallel", dict(resolution=(480, 270), sample_dim=4), 1500),
+    # the two benchmark configurations at their full sizes (the reference's cost is per sample, so sparse
+    # samples of the big frames cost what those of the small ones do)
+    "dragon_area@1080p": ("parallel", dict(resolution=(1920, 1080), sample_dim=4), 1500),
+    "mirrorhall_dof@4k": ("parallel", dict(resolution=(3840, 2160), sample_dim=8), 3000),
     "features_analytic": ("parallel", None, 6000),
     "features_mesh":    ("parallel", None, 3000),
     "features_env":     ("parallel", None, 4000),

@@ -98,7 +98,7 @@ __device__ __forceinline__ void draw_square(const rtamd_scene_desc& S, int sid, 
 
 // ---------------------------------------------------------------- work counters
 #ifdef RT_PHASE_TIMERS
-__device__ unsigned long long g_phase_cycles[48];
+__device__ unsigned long long g_phase_cycles[64];
 // coarse marks along a wave's life (profiling builds): cycles since the previous mark go to `slot`
 struct WaveMarks {
     long long mark_t = 0;
@@ -649,6 +649,20 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
     PhaseClock clk;
     clk.start(unlimited ? 36 : 8);
     clk.count(PH_QUERIES);
+#ifdef RT_PHASE_TIMERS
+    // walk statistics: fresh = 1 while a walk that started at the root has not reached its first leaf, 2 the same
+    // for a walk that started from a stack entry handed over; levels = interior steps of such a walk so far
+    int fresh = walking ? 1 : 0, levels = 0;
+    auto note_start = [&](int kind) {
+        fresh = kind; levels = 0;
+        if (kind == 1) { atomicAdd(&g_phase_cycles[50], 1ull); if (t_near < 0.0f) atomicAdd(&g_phase_cycles[51], 1ull); }
+        else atomicAdd(&g_phase_cycles[58], 1ull);
+    };
+    if (walking) note_start(1);
+#define RT_NOTE_START(kind) note_start(kind)
+#else
+#define RT_NOTE_START(kind)
+#endif
 
     auto entry_at = [&](int i) -> u32x2 { return i < LDS_STACK ? lds[i * 64 + lane] : deep[i - LDS_STACK]; };
     auto pop = [&]() {
@@ -671,6 +685,7 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
             t_near = near2w; t_far = t_exit = exit2w;
             sp = 0; sb = 0; owner = lane + 64;
             found = false; walking = true;
+            RT_NOTE_START(1);
         }
         if (TWO) {
             // second rays that wait behind a first ray still being walked go to lanes with nothing to do
@@ -699,6 +714,7 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
                     node = T.shadow_root; t_near = n_near; t_far = n_exit; t_exit = n_exit;
                     sp = 0; sb = 0;
                     found = false; walking = true;
+                    RT_NOTE_START(1);
                 }
             }
         }
@@ -741,6 +757,7 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
                     node = n_node; t_near = n_t; t_far = n_exit; t_exit = n_exit;
                     sp = 0; sb = 0;
                     found = false; walking = true;
+                    RT_NOTE_START(2);
                 }
             }
         }
@@ -748,7 +765,11 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
 #ifdef RT_PHASE_TIMERS
         {
             const unsigned long long n_walking = __popcll(__ballot(walking));
-            if (lane == 0) { atomicAdd(&g_phase_cycles[28], 1ull); atomicAdd(&g_phase_cycles[29], n_walking); }
+            const unsigned long long n_fresh1 = __popcll(__ballot(walking && fresh == 1)), n_fresh2 = __popcll(__ballot(walking && fresh == 2));
+            if (lane == 0) {
+                atomicAdd(&g_phase_cycles[28], 1ull); atomicAdd(&g_phase_cycles[29], n_walking);
+                atomicAdd(&g_phase_cycles[48], n_fresh1); atomicAdd(&g_phase_cycles[49], n_fresh2);
+            }
         }
 #endif
         int32_t first = 0, count = 0;
@@ -757,6 +778,9 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
         if (walking) {
             auto step = [&](const rtamd_kdnode& nd) {
                 w.node();
+#ifdef RT_PHASE_TIMERS
+                levels++;
+#endif
                 const int ax = nd.b;
                 const float split = (float)nd.split;
                 const float o = axis_of_f(ox, oy, oz, ax);
@@ -795,6 +819,13 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
                 }
                 if (parked) break;
                 w.leaf();
+#ifdef RT_PHASE_TIMERS
+                if (fresh) {
+                    atomicAdd(&g_phase_cycles[fresh == 1 ? 55 : 59], (unsigned long long)levels);
+                    atomicAdd(&g_phase_cycles[fresh == 1 ? 56 : 60], (unsigned long long)sp);     // entries pushed on the way
+                    fresh = 0;
+                }
+#endif
                 first = nd.a;
                 count = nd.b >> 2;
                 bool touched = false;
@@ -820,6 +851,24 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
         const bool at_leaf = walking && !parked;
         const unsigned long long p16 = __ballot(at_leaf && count <= 16);
         const unsigned long long p32 = __ballot(at_leaf && count > 16 && count <= 32);
+#ifdef RT_PHASE_TIMERS
+        {
+            unsigned long long rest = p16;
+            const unsigned long long n_rays = __popcll(rest);
+            unsigned long long n_leaves = 0, biggest = 0;
+            while (rest) {
+                const int32_t lf = bcast_i(first, first_lane(rest));
+                const unsigned long long same = __ballot(at_leaf && count <= 16 && first == lf);
+                rest &= ~same;
+                n_leaves++;
+                biggest = max(biggest, (unsigned long long)__popcll(same));
+            }
+            if (lane == 0 && n_rays) {
+                atomicAdd(&g_phase_cycles[52], n_rays); atomicAdd(&g_phase_cycles[53], n_leaves); atomicAdd(&g_phase_cycles[54], 1ull);
+                atomicAdd(&g_phase_cycles[57], biggest);
+            }
+        }
+#endif
         if (p16) packed_leaves<COUNT, true, 16>(S, false, p16, r, first, count, w, found, best);
         clk.lap(PH_PACK16);
         if (p32) packed_leaves<COUNT, true, 32>(S, false, p32, r, first, count, w, found, best);
@@ -1951,10 +2000,13 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
             double near1 = 0, exit1 = 0, near2 = 0, exit2 = 0;
             const bool casts = T.shadow_casters != RTAMD_CASTERS_NONE;
             const bool in1 = casts && lit && root_box(T, q1, near1, exit1);
-            const bool in2 = casts && facing && root_box(T, q2, near2, exit2);
+            // (a light ray that reaches the light before it reaches the box - a hit point beyond the emitter,
+            // whose ray would enter the box on its extension - has nothing of this tree in front of the light)
+            const bool in2 = casts && facing && root_box(T, q2, near2, exit2) && (!bounded || near2 < limit);
             const bool free2 = !bounded || (exit2 * (1.0 + 1e-9) + 1e-9 < limit);
-            // (fused_always: the emitter lies outside the tree's box by a margin, so every light ray
-            // leaves the box before it reaches the light, whatever rounding does to the two distances)
+            // (fused_always: the emitter lies outside the tree's box by a margin along some axis, so a light
+            // ray that is inside the box before its limit has left it again by then, whatever rounding does
+            // to the two distances)
             if (stk.fused_always || !__ballot(in2 && !free2)) {
                 w.mark(34);
                 // light.in_shadow for both rays: the analytic objects first, the tree last

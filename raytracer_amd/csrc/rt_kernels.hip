@@ -529,10 +529,10 @@ int rtamd_abi_version(void) { return RTAMD_ABI_VERSION; }
 #ifdef RT_PHASE_TIMERS
 // profiling builds only: read (and clear) the per-phase cycle table
 int rtamd_debug_phase_cycles(unsigned long long* out32, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(rt::g_phase_cycles), 48 * sizeof(unsigned long long));
+    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(rt::g_phase_cycles), 64 * sizeof(unsigned long long));
     if (e != hipSuccess) return hip_fail(e, "reading the phase table");
     if (reset) {
-        unsigned long long zero[48] = {0};
+        unsigned long long zero[64] = {0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(rt::g_phase_cycles), zero, sizeof(zero));
         if (e != hipSuccess) return hip_fail(e, "clearing the phase table");
     }

@@ -14,7 +14,9 @@ GOLDEN_SCENES = ("foursphere", "glossyreflective", "mirrorhall", "mirrorhall_dof
                  "k", "mirror", "mirroralt", "features_nested",
                  "fuzz_0", "fuzz_1", "fuzz_2", "fuzz_3", "fuzz_4", "fuzz_5", "fuzz_6", "fuzz_7", "fuzz_8",
                  "fuzzmesh_0", "fuzzmesh_1", "fuzzmesh_2", "fuzzmesh_10",
-                 "glossyreflective@realtime", "mirrorhall@realtime")
+                 "glossyreflective@realtime", "mirrorhall@realtime",
+                 # benchmark configurations 4 and 5 at their full sizes (sparse samples of the big frames)
+                 "dragon_area@1080p", "mirrorhall_dof@4k")
 
 # float comparison bound for radiance: the tolerance of the task statement is 1e-4
 # relative per channel (fp32 device vs Python float64); this build computes in double, so

@@ -711,8 +711,8 @@ def test_executed_work_counters_on_the_dragon(torch_gpu):
         ds.render_tiles(cam, world.seed, fb.tile_ids, 0, 16, sum_rgb8=fb.sum_rgb8, count_executed=True, count_work=True)
 
 
-@pytest.mark.parametrize("case", ("panel_inside_the_box", "panel_beside_the_box", "panel_far_from_the_box", "phong_dragon",
-                                  "teapot_smooth", "tiny_instance"))
+@pytest.mark.parametrize("case", ("panel_inside_the_box", "panel_beside_the_box", "panel_far_from_the_box",
+                                  "panel_between_floor_and_box", "phong_dragon", "teapot_smooth", "tiny_instance"))
 def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
     """One kd-tree, an ambient occluder, one light, AreaLightTracer: the whole-frame kernel traces
     both shadow rays of a hit in one query on the mesh's shadow tree - unless some light ray
@@ -763,11 +763,18 @@ def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
             panel = Rectangle(np.array((-3., 4., z)), 3, 2, np.array((0., 0., -1.)), np.array((1., 0., 0.)),
                               Emissive(30., np.array((1., .96, .9))), sampler)
             world.lights = [AreaLight(panel.material, panel, 6.)]
+        elif case == "panel_between_floor_and_box":
+            # an emitter beside the box along x (the box ends at x = 7.05) that faces +z: the floor beyond it
+            # (x > 9.6, z > 0) is lit, and the rays from there to the emitter point at the box behind it -
+            # they reach the light first, so nothing of the tree may shadow them
+            panel = Rectangle(np.array((7.6, .5, 0.)), 2, 2, np.array((0., 0., 1.)), np.array((1., 0., 0.)),
+                              Emissive(30., np.array((1., .96, .9))), sampler)
+            world.lights = [AreaLight(panel.material, panel, 6.)]
         else:
             tree = world.objects[0]
             shiny = Phong(ka=.6, kd=.7, ks=.5, exp=30, cd=np.array((1., .84, .1)))
             for box in tree.boxes:
                 box.obj.material = shiny
-        tiles, samples = 120, None
+        tiles, samples = (576 if case == "panel_between_floor_and_box" else 120), None
     world.invalidate()
     check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), tiles, samples, case)

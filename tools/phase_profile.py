@@ -67,7 +67,7 @@ def main():
         world.invalidate()
     job = distributed.FrameJob(world, 0, 1)
     lib = capi.library()
-    table = (C.c_ulonglong * 48)()
+    table = (C.c_ulonglong * 64)()
     job.render()
     torch.cuda.synchronize()
     lib.rtamd_debug_phase_cycles(table, 1)
@@ -97,6 +97,17 @@ def main():
                                 "analytic_objects_and_the_rest": t[31] / float(total)}
     if t[28]:
         out["shadow_rounds"] = {"rounds": t[28], "lanes_walking_per_round": t[29] / float(t[28])}
+    if t[50]:
+        # walks of the shadow tree: those that start at the root (a lane's own rays, second rays taken over) and
+        # those that start from a stack entry handed over; "fresh" lane-rounds are spent before the first leaf
+        out["shadow_walks"] = {"root_starts": t[50], "root_starts_with_origin_inside_the_box": t[51], "handed_over_starts": t[58],
+                               "lane_rounds": t[29], "lane_rounds_before_first_leaf_root_starts": t[48],
+                               "lane_rounds_before_first_leaf_handed_over": t[49],
+                               "levels_to_first_leaf_root_starts": t[55] / float(max(t[50], 1)),
+                               "entries_pushed_to_first_leaf_root_starts": t[56] / float(max(t[50], 1)),
+                               "levels_to_first_leaf_handed_over": t[59] / float(max(t[58], 1)),
+                               "packed16_episodes": t[54], "packed16_rays": t[52], "packed16_distinct_leaves": t[53],
+                               "packed16_rays_in_the_fullest_leaf": t[57] / float(max(t[54], 1))}
     print(json.dumps(out, indent=1))
 
 
