@@ -210,25 +210,60 @@ def main():
     # two accumulators in flight: the gather of frame i (int32 per channel on the wire) runs
     # on RCCL's stream while the kernel of frame i+1 renders into the other buffer
     bufs, recv = job.pipeline(2)
+    wire_bytes = job.pipe_wire[0].numel() * job.pipe_wire[0].element_size()
 
-    def run(steps, ev0=None, ev1=None):
+    # Every frame's sums end in host memory on rank 0, as the parent of main.py:99-110 holds them: once a
+    # slot's gather is done its parts are copied into pinned buffers on a side stream, under the kernel
+    # of the next frame (gloo rehearsals gather on the host already).
+    deliver = rank == 0 and backend == "nccl"
+    host_parts, copy_stream, copied = [None, None], None, [None, None]
+    if deliver:
+        copy_stream = torch.cuda.Stream()
+        host_parts = [[torch.empty(job.pipe_wire[0].shape, dtype=torch.int32).pin_memory() for _ in range(world_size)]
+                      for _ in range(2)]
+
+    def to_host(k, parts):
+        """Rank 0: the gathered parts of slot k to pinned host memory, on the side stream."""
+        if not deliver or parts is None:
+            return
+        done = torch.cuda.Event()
+        done.record()                               # the current stream is ordered after the gather here
+        copy_stream.wait_event(done)
+        with torch.cuda.stream(copy_stream):
+            for dst, src in zip(host_parts[k], parts):
+                dst.copy_(src, non_blocking=True)
+            copied[k] = torch.cuda.Event()
+            copied[k].record()
+
+    def run(steps, ev0=None, ev1=None, stall=None):
         pending = [None, None]
         for i in range(steps):
             k = i % 2
             if pending[k] is not None:
-                pending[k].wait()               # the slot's previous gather has read its wire buffer
-            bufs[k].zero_()
+                t_wait = time.perf_counter()
+                if stall is not None:
+                    stall["gpu"][0][i].record()
+                parts = pending[k].wait()           # the slot's previous gather has read its wire buffer
+                if stall is not None:
+                    stall["gpu"][1][i].record()
+                    stall["host_s"] += time.perf_counter() - t_wait
+                to_host(k, parts)
+            # (the slot's sums were cleared by the pack pass of its previous frame)
             # events bracket the tile kernel on the stream it is launched on (torch's current stream)
             if ev0 is not None:
                 ev0[i].record()
             job.render_fn(job.tile_ids, bufs[k], None)
             if ev1 is not None:
                 ev1[i].record()
-            pending[k] = distributed.gather_to_root(job.send(k), parts=recv[k], async_op=True)
+            if copied[k] is not None:
+                torch.cuda.current_stream().wait_event(copied[k])   # the slot's wire / receive buffers are free again
+                copied[k] = None
+            pending[k] = distributed.gather_to_root(job.send(k, clear=True), parts=recv[k], async_op=True)
         parts = None
         for k in ((steps - 2) % 2, (steps - 1) % 2) if steps > 1 else (0,):
             if pending[k] is not None:
                 parts = pending[k].wait()       # the last frame's gather is waited for last
+                to_host(k, parts)
         return parts
 
     run(args.warmup)                            # same code path as the timed steps
@@ -240,12 +275,24 @@ def main():
     ds.read_counters(reset=True)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stall = {"host_s": 0.0, "gpu": ([torch.cuda.Event(enable_timing=True) for _ in range(args.steps)],
+                                    [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)])}
     t0 = time.perf_counter()
-    parts = run(args.steps, ev0, ev1)
+    parts = run(args.steps, ev0, ev1, stall)
     barrier()
     elapsed = time.perf_counter() - t0
     counters = ds.read_counters(reset=True)
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    # how long this rank's stream stood still behind a gather before it could reuse a slot (per step)
+    stall_gpu_ms = sum(a.elapsed_time(b) for a, b in list(zip(*stall["gpu"]))[2:]) / args.steps
+    last_wire = job.pipe_wire[(args.steps - 1) % 2].clone()
+    per_rank = torch.tensor([kernel_ms, stall_gpu_ms, stall["host_s"] * 1e3 / args.steps, elapsed * 1e3 / args.steps,
+                             float(len(job.tiles))], dtype=torch.float64, device="cuda")
+    rank_stats = [per_rank]
+    if world_size > 1:
+        rank_stats = [torch.zeros_like(per_rank) for _ in range(world_size)]
+        dist.all_gather(rank_stats, per_rank)
+    rank_stats = [[float(x) for x in r.cpu()] for r in rank_stats]
 
     # whole-job numbers: max time over ranks, sum of rays over ranks
     stats = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
@@ -264,7 +311,7 @@ def main():
     ds.render_tiles(cam, world.seed, job.tile_ids, 0, n_samples, sum_rgb8=probe, count_executed=True)
     torch.cuda.synchronize()
     done = ds.read_counters(reset=True, executed=True)
-    same_frame = bool(torch.equal(probe, bufs[(args.steps - 1) % 2]))     # against the last timed frame
+    same_frame = bool(torch.equal(probe.clamp(-2147483648, 2147483647).to(torch.int32), last_wire))   # against the last timed frame
     probe.zero_()
     ds.render_tiles(cam, world.seed, job.tile_ids, 0, n_samples, sum_rgb8=probe, count_work=True)
     torch.cuda.synchronize()
@@ -283,6 +330,8 @@ def main():
     if world_size > 1:
         dist.barrier()
     if rank == 0:
+        if deliver:
+            parts = host_parts[(args.steps - 1) % 2]        # the last frame as it was delivered to the host
         frame = job.finish(parts)
         line = {
             "metric": "Mrays/s (whole node) on dragon.obj kd-tree scene",
@@ -326,6 +375,15 @@ def main():
                                  "executing vector-ALU instructions; reference_work is the reference algorithm's "
                                  "traffic for the same rays, most of which the kernel culls - not a rate it reaches"},
             "cpu_baseline": cpu,
+            # per rank: the tile kernel, how long the rank's stream and its host thread stood still behind a
+            # gather, its own time per step, its share of the tiles; bytes it puts on the wire per frame
+            "ranks": {"kernel_ms": [r[0] for r in rank_stats], "gather_stall_gpu_ms": [r[1] for r in rank_stats],
+                      "gather_stall_host_ms": [r[2] for r in rank_stats], "ms_per_step": [r[3] for r in rank_stats],
+                      "tiles": [int(r[4]) for r in rank_stats], "wire_bytes_per_rank_and_frame": wire_bytes,
+                      "per_step_launches": "tile kernel, pack (saturate to int32 + clear), gather"},
+            "timed_region": "K frames: tile kernel, pack, gather to rank 0, copy of the gathered sums to pinned host "
+                            "memory on rank 0 (side stream)" + ("" if deliver else " [host copy skipped: gloo rehearsal]") +
+                            "; excludes the un-permute and divide/clamp of main.py:99-106, done once on the host after timing",
         }
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
@@ -338,7 +396,12 @@ def cpu_baseline(world, ds, cam, n_samples, target_seconds):
     import numpy
     from oracle import oracle
     from raytracer_amd import runtime
-    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    # every CPU this process may run on; a box that hands the job a share of its CPUs says so through
+    # OMP_NUM_THREADS (the GPU boxes give one GPU's job 16 of the machine's CPUs), and more threads than that
+    # share would only queue up behind each other
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = int(os.environ.get("RTAMD_CPU_THREADS") or os.environ.get("OMP_NUM_THREADS") or avail)
+    threads = max(1, min(avail, share))
     osc = oracle.OracleScene(ds.flat)
     tx, ty = runtime.tile_grid(cam.width, cam.height)
     order = numpy.random.RandomState(11).permutation(tx * ty).astype(numpy.int32)
@@ -356,8 +419,9 @@ def cpu_baseline(world, ds, cam, n_samples, target_seconds):
     c = osc.read_counters(reset=True)
     rays = c["closest"] + c["shadow"]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "%d random 8x8 tiles x %d spp = %d samples, %d rays, %.1f s"
-                      % (len(tiles), n_samples, c["samples"], rays, dt)}
+            "host_cpus": os.cpu_count(), "cpus_available_to_this_job": min(avail, share),
+            "sample": "%d random 8x8 tiles x %d spp = %d samples, %d rays, %.1f s; samples handed to the threads in "
+                      "chunks of 1000 (the job size of main.py:92)" % (len(tiles), n_samples, c["samples"], rays, dt)}
 
 
 if __name__ == "__main__":

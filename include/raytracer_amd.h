@@ -423,6 +423,14 @@ int rtamd_render_tiles(rtamd_scene *scene, const rtamd_camera *camera, uint64_t 
                        int64_t *sum_rgb8, double *sum_sq,
                        uint64_t *counters, uint32_t flags, void *stream);
 
+/* A worker's results on their way to the parent (main.py:88-90 puts them on the pixel queue,
+ * main.py:99-110 adds them up): between a rank's rtamd_render_tiles and the gather that brings its
+ * sums to rank 0.  wire[i] = sum_rgb8[i] saturated to int32, for i < n_values (a sum only leaves the
+ * int32 range when samples were infinite, and such a pixel is clamped to 0 or 255 on arrival,
+ * main.py:104-106); with clear != 0 sum_rgb8 is zeroed in the same pass, ready for the next frame.
+ * Device pointers, asynchronous on `stream`. */
+int rtamd_pack_sums(int64_t *sum_rgb8, int32_t *wire, int64_t n_values, int32_t clear, void *stream);
+
 /* ---- device-side kd-tree build ------------------------------------------------------
  * KDTree(BoundingBoxes(boxes))  (kdtree.py:8-24, :27-52, :56-69, :92-131): builds, on the
  * device, exactly the tree the reference's recursion builds from n axis-aligned boxes
@@ -459,7 +467,9 @@ int rtamd_kd_build(const double *box_lo, const double *box_hi, int64_t n_boxes,
 
 /* The same build without a workspace argument and without any allocation.  It has no
  * counterpart in the reference; it exists for callers that cannot allocate device memory
- * (code under HIP graph capture set-up, serving loops and harnesses that forbid hipMalloc).
+ * (serving loops and harnesses that forbid hipMalloc, set-up code that runs where allocation is
+ * not possible).  Like rtamd_kd_build it synchronises `stream` and copies a few totals to the host
+ * after every tree level, so it cannot itself be captured into a HIP graph.
  * The buffers live in a static array of the library's code object (11 MiB, held by every GPU
  * the library runs on until the process ends), which limits it to n_boxes <= 8192, 24576
  * references per tree level, 32768 nodes and 32768 leaf references; larger inputs fail with
@@ -483,7 +493,8 @@ const char *rtamd_kd_last_error(void);
  * node_link = index of the right child, or node_axis -1 for a leaf whose number is node_link;
  * leaf k holds the boxes leaf_row[leaf_offset[k] .. leaf_offset[k+1]).  With the five output
  * arrays NULL only the sizes are worked out (n_nodes, n_leaves, n_rows, depth = levels).
- * RTAMD_EUNSUPPORTED: within max_depth levels some leaf would keep more than max_leaf_rows. */
+ * RTAMD_EUNSUPPORTED: within max_depth levels some leaf would keep more than max_leaf_rows;
+ * RTAMD_EINVAL also when the host runs out of memory. */
 int rtamd_shadow_tree_build(const double *box_lo, const double *box_hi, int64_t n_boxes, int32_t max_depth,
                             int32_t leaf_rows, int32_t max_leaf_rows, double step_cost,
                             int32_t *node_axis, double *node_split, int32_t *node_link, int64_t max_nodes,

@@ -125,7 +125,7 @@ class KDTree(GeometryObject):
             try:
                 self._build_on_device()
                 return
-            except RuntimeError as e:
+            except (RuntimeError, MemoryError) as e:    # (torch's out-of-memory error is a RuntimeError)
                 # RTAMD_KD_BUILD=auto: the device build is an accelerator for the host build below, which
                 # yields the same arrays; an explicit RTAMD_KD_BUILD=device fails loudly
                 if KD_BUILD == "device":
@@ -195,8 +195,18 @@ class KDTree(GeometryObject):
                                     cap_items, C.byref(n_nodes), C.byref(n_refs), C.byref(depth),
                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             if rc == capi.EUNSUPPORTED and level_factor < 64:
-                level_factor *= 2           # a level (or the tree) outgrew the buffers
-                continue
+                # only a level (or the tree) that outgrew the buffers is worth a larger workspace, and only
+                # while that workspace fits in the memory the device has free
+                why = (lib.rtamd_kd_last_error() or b"").decode()
+                outgrown = ("holds more references" in why or "more nodes" in why or "more leaf references" in why)
+                bigger = C.c_size_t()
+                cap2 = max(2 * level_factor * n, 1024)
+                lib.rtamd_kd_build_workspace_bytes(cap2, 2 * cap2, 2 * cap2, C.byref(bigger))
+                free_bytes = torch.cuda.mem_get_info(dev)[0] + need.value
+                if outgrown and bigger.value + 7 * 4 * 2 * cap2 + 4 * 2 * cap2 < free_bytes:
+                    level_factor *= 2
+                    del workspace, arrays
+                    continue
             capi.check_kd(rc, lib)
             break
         nn, nr = n_nodes.value, n_refs.value

@@ -108,7 +108,7 @@ class SampleOut(C.Structure):
 #: every symbol include/raytracer_amd.h declares
 EXPORTS = ("rtamd_abi_version", "rtamd_device_check", "rtamd_last_error",
            "rtamd_scene_create", "rtamd_scene_destroy", "rtamd_render_pixels",
-           "rtamd_trace_rays", "rtamd_render_tiles",
+           "rtamd_trace_rays", "rtamd_render_tiles", "rtamd_pack_sums",
            "rtamd_kd_build_workspace_bytes", "rtamd_kd_build", "rtamd_kd_build_static", "rtamd_kd_last_error",
            "rtamd_shadow_tree_build")
 
@@ -142,6 +142,8 @@ def bind(lib):
     lib.rtamd_render_tiles.restype = C.c_int
     lib.rtamd_render_tiles.argtypes = [vp, C.POINTER(Camera), u64, i64, vp, i32, i32,
                                        C.POINTER(SampleOut), vp, vp, vp, u32, vp]
+    lib.rtamd_pack_sums.restype = C.c_int
+    lib.rtamd_pack_sums.argtypes = [vp, vp, i64, i32, vp]
     lib.rtamd_kd_build_workspace_bytes.restype = C.c_int
     lib.rtamd_kd_build_workspace_bytes.argtypes = [i64, i64, i64, C.POINTER(C.c_size_t)]
     lib.rtamd_kd_build.restype = C.c_int

@@ -99,6 +99,7 @@ __device__ __forceinline__ void draw_square(const rtamd_scene_desc& S, int sid, 
 // ---------------------------------------------------------------- work counters
 #ifdef RT_PHASE_TIMERS
 __device__ unsigned long long g_phase_cycles[64];
+__device__ unsigned long long g_phase_hist[64];   // shadow-tree queries by their number of rays (8 per bucket): queries, rounds, cycles, lane-rounds
 // coarse marks along a wave's life (profiling builds): cycles since the previous mark go to `slot`
 struct WaveMarks {
     long long mark_t = 0;
@@ -659,6 +660,9 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
         else atomicAdd(&g_phase_cycles[58], 1ull);
     };
     if (walking) note_start(1);
+    const int q_rays = (int)__popcll(__ballot(walking)) + (int)__popcll(__ballot(TWO && pending2));
+    const long long q_start = clock64();
+    unsigned long long q_rounds = 0, q_lane_rounds = 0;
 #define RT_NOTE_START(kind) note_start(kind)
 #else
 #define RT_NOTE_START(kind)
@@ -766,6 +770,7 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
         {
             const unsigned long long n_walking = __popcll(__ballot(walking));
             const unsigned long long n_fresh1 = __popcll(__ballot(walking && fresh == 1)), n_fresh2 = __popcll(__ballot(walking && fresh == 2));
+            q_rounds++; q_lane_rounds += n_walking;
             if (lane == 0) {
                 atomicAdd(&g_phase_cycles[28], 1ull); atomicAdd(&g_phase_cycles[29], n_walking);
                 atomicAdd(&g_phase_cycles[48], n_fresh1); atomicAdd(&g_phase_cycles[49], n_fresh2);
@@ -919,6 +924,13 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
         }
         clk.lap(PH_POP);
     }
+#ifdef RT_PHASE_TIMERS
+    if (lane == 0) {
+        const int b = min(15, q_rays >> 3);
+        atomicAdd(&g_phase_hist[b], 1ull); atomicAdd(&g_phase_hist[16 + b], q_rounds);
+        atomicAdd(&g_phase_hist[32 + b], (unsigned long long)(clock64() - q_start)); atomicAdd(&g_phase_hist[48 + b], q_lane_rounds);
+    }
+#endif
     found = out_found;
     best.t = out_t;
     if (TWO) *found2 = out_found2;

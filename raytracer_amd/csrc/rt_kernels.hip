@@ -402,6 +402,18 @@ __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES_ANALYTIC) void refill_kernel(co
     }
 }
 
+// A frame's integer sums on their way to the parent (the gather of the multi-GPU job): every 64-bit
+// sum saturated to the int32 it travels as, and the sum cleared for the next frame if asked.  One pass
+// instead of a clamp, a narrowing copy and a memset.
+__global__ __launch_bounds__(256) void pack_sums_kernel(int64_t* __restrict__ sums, int32_t* __restrict__ wire, int64_t n, int clear) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t v = sums[i];
+        wire[i] = v > 2147483647LL ? 2147483647 : (v < -2147483648LL ? (int32_t)0x80000000 : (int32_t)v);
+        if (clear) sums[i] = 0;
+    }
+}
+
 thread_local char g_error[512] = "";
 
 int fail(int code, const char* fmt, const char* detail = "") {
@@ -531,8 +543,12 @@ int rtamd_abi_version(void) { return RTAMD_ABI_VERSION; }
 int rtamd_debug_phase_cycles(unsigned long long* out32, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(rt::g_phase_cycles), 64 * sizeof(unsigned long long));
     if (e != hipSuccess) return hip_fail(e, "reading the phase table");
+    e = hipMemcpyFromSymbol(out32 + 64, HIP_SYMBOL(rt::g_phase_hist), 64 * sizeof(unsigned long long));
+    if (e != hipSuccess) return hip_fail(e, "reading the query histogram");
     if (reset) {
         unsigned long long zero[64] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(rt::g_phase_hist), zero, sizeof(zero));
+        if (e != hipSuccess) return hip_fail(e, "clearing the query histogram");
         e = hipMemcpyToSymbol(HIP_SYMBOL(rt::g_phase_cycles), zero, sizeof(zero));
         if (e != hipSuccess) return hip_fail(e, "clearing the phase table");
     }
@@ -857,6 +873,18 @@ int rtamd_render_tiles(rtamd_scene* scene, const rtamd_camera* camera, uint64_t 
     A.sum_sq = sum_sq;
     A.counters = reinterpret_cast<unsigned long long*>(counters);
     return launch<MODE_TILES>(scene->desc, scene->extended, scene->tree_objects, scene->max_tree_depth, scene->bounces, scene->fused_always, A, flags, stream);
+}
+
+int rtamd_pack_sums(int64_t* sum_rgb8, int32_t* wire, int64_t n_values, int32_t clear, void* stream) {
+    if (n_values < 0) return fail(RTAMD_EINVAL, "negative count%s");
+    if (n_values == 0) return RTAMD_OK;
+    if (!sum_rgb8 || !wire) return fail(RTAMD_EINVAL, "null buffer%s");
+    const int64_t blocks = (n_values + 255) / 256;
+    hipLaunchKernelGGL(pack_sums_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), sum_rgb8, wire, n_values, (int)clear);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return RTAMD_OK;
 }
 
 }  // extern "C"

@@ -106,6 +106,7 @@ extern "C" int rtamd_shadow_tree_build(const double* box_lo, const double* box_h
     if (!box_lo || !box_hi || n_boxes <= 0 || n_boxes > 0x7fffffffLL || !n_nodes || !n_leaves || !n_rows || !depth ||
         max_depth < 0 || leaf_rows < 1 || max_leaf_rows < leaf_rows)
         return RTAMD_EINVAL;
+    try {
     Builder b;
     b.lo = box_lo;
     b.hi = box_hi;
@@ -138,4 +139,7 @@ extern "C" int rtamd_shadow_tree_build(const double* box_lo, const double* box_h
     std::copy(b.leaf_offset.begin(), b.leaf_offset.end(), leaf_offset);
     std::copy(b.leaf_rows_out.begin(), b.leaf_rows_out.end(), leaf_row);
     return RTAMD_OK;
+    } catch (...) {             // the builder's lists are std::vectors: out of host memory
+        return RTAMD_EINVAL;
+    }
 }

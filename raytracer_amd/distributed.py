@@ -35,8 +35,8 @@ def padded_tile_count(width, height, world_size):
 class PendingGather(object):
     """A gather that may still be running on the collective's own stream."""
 
-    def __init__(self, parts, work=None):
-        self.parts, self.work = parts, work
+    def __init__(self, parts, work=None, ran_collective=False):
+        self.parts, self.work, self.ran_collective = parts, work, ran_collective
 
     def wait(self):
         """Order the caller's stream after the gather; returns the root's list (None elsewhere)."""
@@ -46,16 +46,18 @@ class PendingGather(object):
         return self.parts
 
 
-def gather_to_root(local, dist=None, root=0, parts=None, async_op=False):
+def gather_to_root(local, dist=None, root=0, parts=None, async_op=False, always_collective=False):
     """Gather equal-shaped per-rank tensors on `root`; returns the list there, None elsewhere.
 
     `parts` lets the root reuse its receive buffers.  With async_op the collective is only
     enqueued (RCCL runs it on its own stream once the producing kernel is done, so the
-    next frame's kernel overlaps it) and a PendingGather is returned."""
+    next frame's kernel overlaps it) and a PendingGather is returned.  A group of one rank has
+    nothing to gather and skips the collective unless always_collective asks for it (a test of the
+    collective's own path on a box with one GPU)."""
     import torch
     if dist is None:
         import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not always_collective):
         return PendingGather([local]) if async_op else [local]
     world = dist.get_world_size()
     rank = dist.get_rank()
@@ -74,7 +76,7 @@ def gather_to_root(local, dist=None, root=0, parts=None, async_op=False):
         every = [torch.empty_like(local) for _ in range(world)]
         work = dist.all_gather(every, local, async_op=async_op)
         parts = every if rank == root else None
-    return PendingGather(parts, work) if async_op else parts
+    return PendingGather(parts, work, True) if async_op else parts
 
 
 def assemble(parts, width, height, world_size):
@@ -109,6 +111,9 @@ class FrameJob(object):
 
             def render_fn(tile_ids, sum_rgb8, sum_sq):
                 ds.render_tiles(cam, world.seed, tile_ids, 0, self.n_samples, sum_rgb8=sum_rgb8, sum_sq=sum_sq)
+            self.ds = ds
+        else:
+            self.ds = None
         self.render_fn = render_fn
         self.device = device or torch.device("cpu")
         self.tile_ids = torch.as_tensor(self.tiles).to(self.device)
@@ -131,20 +136,27 @@ class FrameJob(object):
         import torch
         bufs = [self.sum_rgb8] + [torch.zeros_like(self.sum_rgb8) for _ in range(depth - 1)]
         self.pipe_bufs = bufs
-        self.pipe_clamped = [torch.zeros_like(b) for b in bufs]
         self.pipe_wire = [torch.zeros(b.shape, dtype=torch.int32, device=b.device) for b in bufs]
         is_root = self.rank == 0 and self.world_size > 1
         recv = [[torch.empty_like(w) for _ in range(self.world_size)] if is_root else None for w in self.pipe_wire]
         return bufs, recv
 
-    def send(self, slot):
+    def send(self, slot, clear=False):
         """The slot's accumulator as it travels: int32 per channel (saturated), half the
         bytes of the kernel's 64-bit sums.  A pixel's sum only leaves the int32 range when
-        samples were infinite, and such a pixel is clamped to 0 or 255 on arrival anyway."""
+        samples were infinite, and such a pixel is clamped to 0 or 255 on arrival anyway.
+        `clear` zeroes the accumulator for the slot's next frame.  On the GPU this is one pass of
+        the library's pack kernel (rtamd_pack_sums); accumulators of a caller's own render_fn on
+        the host (the CPU tests of the job's logic) take the same steps with torch."""
         import torch
-        torch.clamp(self.pipe_bufs[slot], -2147483648, 2147483647, out=self.pipe_clamped[slot])
-        self.pipe_wire[slot].copy_(self.pipe_clamped[slot])
-        return self.pipe_wire[slot]
+        buf, wire = self.pipe_bufs[slot], self.pipe_wire[slot]
+        if self.ds is not None and buf.is_cuda:
+            self.ds.pack_sums(buf, wire, clear=clear)
+        else:
+            wire.copy_(torch.clamp(buf, -2147483648, 2147483647))
+            if clear:
+                buf.zero_()
+        return wire
 
     def finish(self, parts):
         """On rank 0: the frame as uint8 (height, width, 3), by the rules of main.py:99-106

@@ -175,6 +175,13 @@ class DeviceScene(object):
                 self.counters.data_ptr(), self._flags(count_work, count_executed), self.stream_ptr()), self.lib)
 
 
+    def pack_sums(self, sum_rgb8, wire, clear=False):
+        """Asynchronous: wire (int32) = the 64-bit sums saturated; `clear` zeroes the sums in the same pass."""
+        with self.on_device():
+            capi.check(self.lib.rtamd_pack_sums(sum_rgb8.data_ptr(), wire.data_ptr(), sum_rgb8.numel(), 1 if clear else 0,
+                                                self.stream_ptr()), self.lib)
+
+
 def device_scene(world):
     """The world's DeviceScene, created on first use.  A world is immutable once built
     (as in the reference, where workers fork a copy); call `world.invalidate()` after

@@ -58,9 +58,10 @@ def _worker(rank, world_size, port, scene, overrides, out_path):
         k = i % 2
         if pending[k] is not None:
             pending[k].wait()
-        bufs[k].zero_()
+        # (a slot's sums start at zero and are cleared again by the pass that packs them for the wire)
         job.render_fn(job.tile_ids, bufs[k], None)
-        pending[k] = distributed.gather_to_root(job.send(k), parts=recv[k], async_op=True)
+        pending[k] = distributed.gather_to_root(job.send(k, clear=True), parts=recv[k], async_op=True)
+        assert int(bufs[k].abs().sum()) == 0
     pending[1].wait()
     frame = job.finish(pending[0].wait())
     if rank == 0:
@@ -116,7 +117,7 @@ def test_partition_covers_every_tile_once():
                 assert max(sizes) - min(sizes) <= max(2, tx * ty // (world_size * 20))   # balanced
 
 
-@pytest.mark.parametrize("n", (2, 4))
+@pytest.mark.parametrize("n", (2, 4, 8))
 def test_bench_starts_its_own_ranks(n):
     """`python bench.py --gpus N` without a launcher starts N ranks itself (rehearsed without
     a GPU: rendezvous and one collective over gloo) and relays rank 0's JSON line."""
@@ -167,6 +168,57 @@ def _nccl_worker(rank, world_size, port, out_path):
         numpy.save(out_path, frame)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _nccl_single_worker(rank, port, out_path):
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from raytracer_amd.world import World
+    from raytracer_amd import distributed
+    world = World.__new__(World)
+    world.overrides = dict(resolution=(88, 60), sample_dim=2)
+    World.__init__(world, viewmode="parallel", buildfunction="cornellbox_area", seed=3)
+    job = distributed.FrameJob(world, 0, 1)
+    bufs, _ = job.pipeline(2)
+    recv = [[torch.empty_like(w)] for w in job.pipe_wire]
+    pending = [None, None]
+    for i in range(4):                      # frames in flight, as bench.py runs them
+        k = i % 2
+        if pending[k] is not None:
+            pending[k].wait()
+        job.render_fn(job.tile_ids, bufs[k], None)
+        pending[k] = distributed.gather_to_root(job.send(k, clear=True), parts=recv[k], async_op=True, always_collective=True)
+    pending[0].wait()
+    parts = pending[1].wait()
+    torch.cuda.synchronize()
+    assert parts is recv[1] and pending[1].ran_collective
+    numpy.save(out_path, job.finish(parts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_gather_with_one_rank(tmp_path):
+    """The gather as bench.py issues it (device_id at initialisation, asynchronous, into a reused receive
+    list, int32 wire buffers packed by the library) run through RCCL itself on the one GPU of the box:
+    a group of one rank, the collective forced (a group of one normally skips it)."""
+    import torch.multiprocessing as mp
+    from raytracer_amd.world import World
+    from raytracer_amd import runtime
+    out = str(tmp_path / "one.npy")
+    mp.spawn(_nccl_single_worker, args=(_free_port(), out), nprocs=1, join=True)
+    world = World.__new__(World)
+    world.overrides = dict(resolution=(88, 60), sample_dim=2)
+    World.__init__(world, viewmode="parallel", buildfunction="cornellbox_area", seed=3)
+    single, _ = runtime.render_image(world, mode="parallel")
+    assert numpy.array_equal(numpy.load(out), single)
 
 
 @pytest.mark.gpu

@@ -711,21 +711,14 @@ def test_executed_work_counters_on_the_dragon(torch_gpu):
         ds.render_tiles(cam, world.seed, fb.tile_ids, 0, 16, sum_rgb8=fb.sum_rgb8, count_executed=True, count_work=True)
 
 
-@pytest.mark.parametrize("case", ("panel_inside_the_box", "panel_beside_the_box", "panel_far_from_the_box",
-                                  "panel_between_floor_and_box", "phong_dragon", "teapot_smooth", "tiny_instance"))
-def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
-    """One kd-tree, an ambient occluder, one light, AreaLightTracer: the whole-frame kernel traces
-    both shadow rays of a hit in one query on the mesh's shadow tree - unless some light ray
-    ends inside the mesh's box, which sends the wave down the general path.  Both ways, an emitter
-    just outside and well outside the box, a glossy material and a smooth mesh: timed =
-    executed-work = reference-work kernel = oracle."""
+def shadow_path_world(case):
+    """The worlds of test_shadow_tree_paths_of_the_whole_frame_kernel: (world, tiles to check, sample range)."""
     import numpy as np
     import raytracer_amd
     raytracer_amd.activate()
     from geometry import Rectangle
     from light import AmbientOccluder, AreaLight
     from material import Emissive, Phong
-    from raytracer_amd import flatten
     if case == "tiny_instance":
         # the teapot at a fiftieth of its size: in its own space the shadow rays of the ground
         # start hundreds of teapots away, too far for a single-precision walk from their origin:
@@ -776,5 +769,18 @@ def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
             for box in tree.boxes:
                 box.obj.material = shiny
         tiles, samples = (576 if case == "panel_between_floor_and_box" else 120), None
+    return world, tiles, samples
+
+
+@pytest.mark.parametrize("case", ("panel_inside_the_box", "panel_beside_the_box", "panel_far_from_the_box",
+                                  "panel_between_floor_and_box", "phong_dragon", "teapot_smooth", "tiny_instance"))
+def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
+    """One kd-tree, an ambient occluder, one light, AreaLightTracer: the whole-frame kernel traces
+    both shadow rays of a hit in one query on the mesh's shadow tree - unless some light ray
+    ends inside the mesh's box, which sends the wave down the general path.  Both ways, an emitter
+    just outside and well outside the box, a glossy material and a smooth mesh: timed =
+    executed-work = reference-work kernel = oracle."""
+    from raytracer_amd import flatten
+    world, tiles, samples = shadow_path_world(case)
     world.invalidate()
     check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), tiles, samples, case)

@@ -67,7 +67,7 @@ def main():
         world.invalidate()
     job = distributed.FrameJob(world, 0, 1)
     lib = capi.library()
-    table = (C.c_ulonglong * 64)()
+    table = (C.c_ulonglong * 128)()
     job.render()
     torch.cuda.synchronize()
     lib.rtamd_debug_phase_cycles(table, 1)
@@ -108,6 +108,12 @@ def main():
                                "levels_to_first_leaf_handed_over": t[59] / float(max(t[58], 1)),
                                "packed16_episodes": t[54], "packed16_rays": t[52], "packed16_distinct_leaves": t[53],
                                "packed16_rays_in_the_fullest_leaf": t[57] / float(max(t[54], 1))}
+    h = t[64:128]
+    if sum(h[0:16]):
+        out["shadow_queries_by_rays"] = [
+            {"rays": "%d-%d" % (8 * b, 8 * b + 7) if b < 15 else "120-128", "queries": h[b], "rounds_per_query": h[16 + b] / float(h[b]),
+             "cycles_per_query": h[32 + b] / float(h[b]), "lanes_walking_per_round": h[48 + b] / float(max(h[16 + b], 1)),
+             "share_of_query_cycles": h[32 + b] / float(sum(h[32:48]))} for b in range(16) if h[b]]
     print(json.dumps(out, indent=1))
 
 
