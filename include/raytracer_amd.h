@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 6
+#define RTAMD_ABI_VERSION 7
 
 enum {
     RTAMD_OK = 0,
@@ -198,8 +198,7 @@ typedef struct rtamd_tree {
     int32_t ref_offset;     /* first leaf reference of this tree in tri_* arrays   */
     int32_t prim_offset;    /* first primitive of this tree in prim_* arrays       */
     int32_t smooth;         /* vertex normals present: prim_normals holds 9/prim   */
-    int32_t depth;          /* maximum node depth (stack bound), shadow tree and shadow
-                               subtrees (leaf_aabb) included                       */
+    int32_t depth;          /* maximum node depth of the tree proper (the reference's)  */
     int32_t shadow_casters; /* what bit 30 of this tree's tri_prim rows says, in one word:
                                RTAMD_CASTERS_ALL (no row has it), _NONE (every row has it:
                                a mesh with cast_shadow off, geometry.py:433-434) or _MIXED */
@@ -212,7 +211,9 @@ typedef struct rtamd_tree {
                                widened by 4e-5 of the largest coordinate of bbox, reaches
                                into, and the leaves' leaf_aabb rows must be widened
                                alike; ignored without leaf_aabb                     */
-    int32_t reserved;
+    int32_t walk_depth;     /* levels a walk may pass through: `depth`, or more where a shadow
+                               tree or the shadow subtrees of leaves (leaf_aabb) are deeper;
+                               bounds the traversal stack                            */
 } rtamd_tree;
 enum { RTAMD_CASTERS_ALL = 0, RTAMD_CASTERS_NONE = 1, RTAMD_CASTERS_MIXED = 2 };
 
@@ -317,7 +318,7 @@ typedef struct rtamd_scene_desc {
                                            the trees proper, leaves of rows appended to the
                                            triangle tables, each with a box row of its own):
                                            shadow queries that any hit decides walk on into
-                                           it instead of testing the leaf.  rtamd_tree.depth
+                                           it instead of testing the leaf.  rtamd_tree.walk_depth
                                            must then count the levels such a walk can pass */
     const rtamd_transform *transforms;  /* device, NULL when n_transforms == 0: inner levels of nested
                                            Instances */
@@ -489,16 +490,24 @@ const char *rtamd_kd_last_error(void);
  * both sides; a node of at most leaf_rows boxes, or one that no plane improves, becomes a leaf.
  * No counterpart in the reference, whose kdtree.py builds the tree its own walk needs; this is
  * the tree for shadow queries that any hit decides.
+ * With tri_corners ([n_boxes][9] = v0, v1, v2, host memory; may be NULL) a triangle whose box
+ * reaches across a plane is clipped against either side's cell, widened by `slack` (the absolute
+ * amount the boxes were widened by): a side the triangle itself does not come within `slack` of
+ * does not list it, and the box it brings to the other side is that of the part inside, widened by
+ * `slack` again.  Candidate planes and leaf boxes then follow the geometry inside each cell.
  * Nodes come back in preorder (left child = next node): node_axis 0..2 with node_split and
  * node_link = index of the right child, or node_axis -1 for a leaf whose number is node_link;
- * leaf k holds the boxes leaf_row[leaf_offset[k] .. leaf_offset[k+1]).  With the five output
- * arrays NULL only the sizes are worked out (n_nodes, n_leaves, n_rows, depth = levels).
+ * leaf k holds the boxes leaf_row[leaf_offset[k] .. leaf_offset[k+1]) and, if leaf_box is given,
+ * leaf_box[k][6] = lo.xyz hi.xyz around what those rows bring to the leaf (zeros for an empty one;
+ * max_nodes rows).  With the output arrays NULL only the sizes are worked out (n_nodes, n_leaves,
+ * n_rows, depth = levels).
  * RTAMD_EUNSUPPORTED: within max_depth levels some leaf would keep more than max_leaf_rows;
  * RTAMD_EINVAL also when the host runs out of memory. */
 int rtamd_shadow_tree_build(const double *box_lo, const double *box_hi, int64_t n_boxes, int32_t max_depth,
                             int32_t leaf_rows, int32_t max_leaf_rows, double step_cost,
+                            const double *tri_corners, double slack,
                             int32_t *node_axis, double *node_split, int32_t *node_link, int64_t max_nodes,
-                            int64_t *leaf_offset, int32_t *leaf_row, int64_t max_rows,
+                            int64_t *leaf_offset, int32_t *leaf_row, double *leaf_box, int64_t max_rows,
                             int64_t *n_nodes, int64_t *n_leaves, int64_t *n_rows, int32_t *depth);
 
 #ifdef __cplusplus

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(HERE, "csrc", "librtamd.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_BRANCH_LEVELS = 8
 MAX_TREE_DEPTH = 38           # levels a walk may pass through (the kernels' stack holds 40 entries)
 N_COUNTERS = 16
@@ -66,7 +66,7 @@ class KdNode(C.Structure):
 class Tree(C.Structure):
     _fields_ = [("bbox_lo", d3), ("bbox_hi", d3), ("node_offset", C.c_int32),
                 ("ref_offset", C.c_int32), ("prim_offset", C.c_int32), ("smooth", C.c_int32),
-                ("depth", C.c_int32), ("shadow_casters", C.c_int32), ("shadow_root", C.c_int32), ("reserved", C.c_int32)]
+                ("depth", C.c_int32), ("shadow_casters", C.c_int32), ("shadow_root", C.c_int32), ("walk_depth", C.c_int32)]
 
 
 class Texture(C.Structure):
@@ -155,7 +155,8 @@ def bind(lib):
     lib.rtamd_kd_last_error.restype = C.c_char_p
     lib.rtamd_kd_last_error.argtypes = []
     lib.rtamd_shadow_tree_build.restype = C.c_int
-    lib.rtamd_shadow_tree_build.argtypes = [vp, vp, i64, i32, i32, i32, C.c_double, vp, vp, vp, i64, vp, vp, i64,
+    lib.rtamd_shadow_tree_build.argtypes = [vp, vp, i64, i32, i32, i32, C.c_double, vp, C.c_double,
+                                            vp, vp, vp, i64, vp, vp, vp, i64,
                                             C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]
     return lib
 

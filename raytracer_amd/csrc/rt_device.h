@@ -1933,11 +1933,11 @@ __device__ __forceinline__ V3 texture_color(const rtamd_scene_desc& S, int tex, 
 // visited in list order by the whole wave so that the shadow queries stay wave-wide.
 // EXT: `tex` is the texture colour of an SV_Matte hit (material.py:311-326), which scales
 // ka and kd and adds the viewer-side test of :319.
-template <int COUNT, bool EXT, bool TREES, bool ONE_TREE = false>
+template <int COUNT, bool EXT, bool TREES, bool ONE_TREE = false, bool FUSED_OK = ONE_TREE, bool POW_CALL = !TREES>
 __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, bool lit, const rtamd_material& m,
                                 const Hit& h, V3 wo, bool area, V3 tex, Draw& dr, Work<COUNT>& w) {
 #ifndef RT_NO_FUSED_SHADOWS
-    if (ONE_TREE && COUNT != 1 && !EXT && (stk.fused_always || (S.ambient.kind == RTAMD_AMBIENT_OCCLUDER && S.lights[0].cast_shadow &&
+    if (ONE_TREE && FUSED_OK && COUNT != 1 && !EXT && (stk.fused_always || (S.ambient.kind == RTAMD_AMBIENT_OCCLUDER && S.lights[0].cast_shadow &&
                                                                S.leaf_aabb != nullptr))) {
         // One kd-tree, an ambient occluder and one shadow-casting light: the occlusion ray and
         // the light's shadow ray of a hit are both known before either is traced (no draw
@@ -1979,10 +1979,10 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
             V3 term = v3(0, 0, 0);
             if (wanted) {
                 V3 f = ld3(m.diffuse);
-                if (phong) f = f + phong_lobe<!TREES>(ld3(m.specular), m.exp, h.n, wo, wi);
+                if (phong) f = f + phong_lobe<POW_CALL>(ld3(m.specular), m.exp, h.n, wo, wi);
                 V3 Ll = ld3(lt.radiance);
                 if (lt.kind == RTAMD_POINT && lt.attenuation != 0)
-                    Ll = Ll * rt_pow<!TREES>(norm(h.p - ld3(lt.position)) / lt.radius, -lt.attenuation);
+                    Ll = Ll * rt_pow<POW_CALL>(norm(h.p - ld3(lt.position)) / lt.radius, -lt.attenuation);
                 if (lt.kind == RTAMD_AREA && !(dot(ld3(lt.normal), wi) < 0.)) Ll = v3(0, 0, 0);
                 term = (f * Ll) * ndotwi;
                 if (area) {
@@ -2112,10 +2112,10 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
         auto light_term = [&]() {
             V3 f = ld3(m.diffuse);
             if (textured) f = (f * tex) / PI;                                                    // material.py:27-28
-            if (phong) f = f + phong_lobe<!TREES>(ld3(m.specular), m.exp, h.n, wo, wi);
+            if (phong) f = f + phong_lobe<POW_CALL>(ld3(m.specular), m.exp, h.n, wo, wi);
             V3 Ll = ld3(lt.radiance);
             if (lt.kind == RTAMD_POINT && lt.attenuation != 0)                                    // light.py:39-44
-                Ll = Ll * rt_pow<!TREES>(norm(h.p - ld3(lt.position)) / lt.radius, -lt.attenuation);
+                Ll = Ll * rt_pow<POW_CALL>(norm(h.p - ld3(lt.position)) / lt.radius, -lt.attenuation);
             if (lt.kind == RTAMD_AREA && !(dot(ld3(lt.normal), wi) < 0.)) Ll = v3(0, 0, 0);        // light.py:110-114
             term = (f * Ll) * ndotwi;
             if (area) {
@@ -2198,6 +2198,42 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(rt_pow<false>(b.x
 // FEED: where a lane whose path has ended hands its sample in and takes another one, so that the
 // wave's lanes stay filled while paths of different lengths end at different bounces (the kernels
 // that own a list of samples per wave pass one; NoFeed: a lane traces one sample).
+// How a path's radiance is summed.  The kernels carry the product of the bounce weights forward: L += W * local at
+// every hit, W *= (fr * n.wi) / pdf at every bounce.  The reference's recursion sums from the last hit back to the
+// first, L = local + ((fr * L_child) * n.wi) [/ pdf] (material.py:283-289, :385-394, :402-411): the same factors in
+// another order, which agree to rounding except where a glossy lobe is denormal.  Checking builds (-DRT_REF_ORDER, the
+// plain bounce loop only: no two-child materials, no refilled lanes) keep every level's terms and sum in the
+// reference's order, to tell such samples from real differences.
+#ifdef RT_REF_ORDER
+#define RT_REF_ORDER_ON true
+#else
+#define RT_REF_ORDER_ON false
+#endif
+template <bool REFERENCE_ORDER> struct PathSum {
+    __device__ __forceinline__ void add(V3& L, V3 W, V3 x) { L = L + W * x; }
+    __device__ __forceinline__ void bounce(V3, double, double, bool) {}
+    __device__ __forceinline__ void finish(V3&) {}
+};
+template <> struct PathSum<true> {
+    static constexpr int MAX_LEVELS = 40;
+    V3 local[MAX_LEVELS], fr[MAX_LEVELS];
+    double nd[MAX_LEVELS], pdf[MAX_LEVELS];
+    bool divide[MAX_LEVELS];
+    int n = 0;
+    V3 here = {0, 0, 0};            // what the level the lane stands on has added itself
+    __device__ __forceinline__ void add(V3&, V3, V3 x) { here = here + x; }
+    __device__ __forceinline__ void bounce(V3 f, double ndotwi, double p, bool div) {
+        if (n < MAX_LEVELS) { local[n] = here; fr[n] = f; nd[n] = ndotwi; pdf[n] = p; divide[n] = div; n++; here = v3(0, 0, 0); }
+    }
+    __device__ __forceinline__ void finish(V3& L) {
+        L = here;
+        for (int k = n - 1; k >= 0; --k) {
+            const V3 up = (fr[k] * L) * nd[k];
+            L = local[k] + (divide[k] ? up / pdf[k] : up);
+        }
+    }
+};
+
 struct NoFeed {
     static constexpr bool on = false;
     __device__ __forceinline__ void retire(V3) {}
@@ -2205,14 +2241,26 @@ struct NoFeed {
     __device__ __forceinline__ bool more() const { return false; }
 };
 
-template <int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, class FEED = NoFeed, bool NO_BOUNCE = false>
+// PATH_ONLY: the scene runs under the PathTracer (tracer.py:74-88): a hit draws one direction and goes on, no
+// direct lighting - the kernel then holds the closest-hit query and nothing else.
+// ONE_TREE: the scene has exactly one kd-tree object and one light (AREA_ONLY implies it): shadow tests ask the
+// tree last and the loop over the lights is one straight pass.
+template <int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, class FEED = NoFeed, bool NO_BOUNCE = false,
+          bool PATH_ONLY = false, bool ONE_TREE = AREA_ONLY>
 __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStack& stk, bool alive, Ray ray, int depth, Draw& dr,
                          Work<COUNT>& w, Primary& first, FEED& feed) {
     static_assert(!FEED::on || (!EXT && !AREA_ONLY), "sample feeds serve the plain bounce loop");
+    static_assert(!PATH_ONLY || (!EXT && !AREA_ONLY && !NO_BOUNCE), "the path tracer's build is a plain bounce loop");
+    // pow() as a call wherever the body is a loop or holds the general shadow paths (see rt_pow); the area-light
+    // kernels measured faster with it inline
+    constexpr bool POW_CALL = !TREES || !AREA_ONLY;
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
+    PathSum<RT_REF_ORDER_ON && !EXT && !FEED::on> sum;
+#define RT_ADD(X) sum.add(L, W, (X))
+#define RT_BOUNCE(FR, ND, PDF, DIV) sum.bounce((FR), (ND), (PDF), (DIV))
     const int depth0 = depth;
     bool busy = alive;                      // FEED: the lane holds a sample that is not handed in yet
-    const int tracer_kind = AREA_ONLY ? (int)RTAMD_TRACER_AREA : S.tracer_kind;
+    const int tracer_kind = AREA_ONLY ? (int)RTAMD_TRACER_AREA : PATH_ONLY ? (int)RTAMD_TRACER_PATH : S.tracer_kind;
     const bool shade_kind = tracer_kind == RTAMD_TRACER_SHADE || tracer_kind == RTAMD_TRACER_WHITTED;
     const V3 background = shade_kind ? ld3(S.background) : v3(0, 0, 0);
     const bool area = tracer_kind == RTAMD_TRACER_AREA;
@@ -2231,10 +2279,10 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
                 lane_depth = q.depth; has_filter = q.has_filter != 0;
                 alive = true;
             }
-            if (alive && !area && lane_depth > S.depth_limit) { L = L + W * background; alive = false; }
+            if (alive && !area && lane_depth > S.depth_limit) { RT_ADD(background); alive = false; }
             if (!__ballot(alive || n_pending > 0)) break;
         } else if (FEED::on) {
-            if (alive && !area && lane_depth > S.depth_limit) { L = L + W * background; alive = false; }
+            if (alive && !area && lane_depth > S.depth_limit) { RT_ADD(background); alive = false; }
             if (!alive && busy) { feed.retire(L); busy = false; }
             if (feed.next(!alive, ray, dr)) {
                 alive = true; busy = true;
@@ -2245,7 +2293,7 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
             // next pass, and a wave left without a live lane that way goes round once more)
             if (!__ballot(alive) && !feed.more()) break;
         } else {
-            if (alive && !area && depth > S.depth_limit) { L = L + W * background; alive = false; }
+            if (alive && !area && depth > S.depth_limit) { RT_ADD(background); alive = false; }
             if (!__ballot(alive)) break;
         }
         Hit h;
@@ -2254,7 +2302,7 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
         // (with a feed, primary rays taken in later join lanes whose rays have bounced: only the first pass is coherent)
         const bool hit = closest_hit_wave<COUNT, TREES>(S, stk, alive, primary, ray, w, h);
         w.mark(31);     // closest hit, kd query included
-        if (alive && !hit) { L = L + W * background; alive = false; }
+        if (alive && !hit) { RT_ADD(background); alive = false; }
         if (alive && primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; }
         primary = false;
         if (EXT && alive && has_filter) { W = W * powv(filter, h.t); has_filter = false; }
@@ -2266,7 +2314,7 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
             if (shade_kind) e = v3(1., 1., 1.);                                                    // material.py:495-496
             else if (area) e = (-dot(h.n, ray.d) > 0) ? ld3(m.emit) : v3(0, 0, 0);                  // material.py:498-502
             else e = (dot(h.n, ray.d) < 0) ? ld3(m.emit) : v3(0, 0, 0);                             // material.py:504-508
-            L = L + W * e;
+            RT_ADD(e);
             alive = false;
         }
 
@@ -2282,6 +2330,7 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
                 const double pdf = dot(h.n, wi) / PI;
                 const double ndotwi = dot(h.n, wi);
                 W = W * ((ld3(m.diffuse) * ndotwi) / pdf);
+                RT_BOUNCE(ld3(m.diffuse), ndotwi, pdf, true);
                 ray.o = h.p;
                 ray.d = wi;
             }
@@ -2291,8 +2340,8 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
         V3 tex = v3(1, 1, 1);
         if (EXT && alive && m.kind == RTAMD_SV_MATTE)
             tex = texture_color(S, m.texture, local_hit_point(S, S.objects[h.object], ray, h.t));
-        const V3 Ld = direct_light_wave<COUNT, EXT, TREES, AREA_ONLY>(S, stk, alive, m, h, wo, area, tex, dr, w);
-        if (alive) L = L + W * Ld;
+        const V3 Ld = direct_light_wave<COUNT, EXT, TREES, ONE_TREE, AREA_ONLY, POW_CALL>(S, stk, alive, m, h, wo, area, tex, dr, w);
+        if (alive) RT_ADD(Ld);
         // the AreaLightTracer never bounces: leaving here makes the body straight-line code, so
         // nothing is hoisted in front of it and carried (or spilled) through the kd queries
         // (NO_BOUNCE: no material of the scene spawns a child ray - the same holds there)
@@ -2307,6 +2356,7 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
             const double pdf = dot(h.n, wi);
             const V3 fr = ld3(m.reflect) / pdf;
             W = W * (fr * dot(h.n, wi));
+            RT_BOUNCE(fr, dot(h.n, wi), 1.0, false);
             ray.o = h.p;
             ray.d = wi;
         } else if (m.kind == RTAMD_GLOSSY_REFLECTIVE) {
@@ -2319,12 +2369,13 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
             const V3 sp = draw_hemisphere(S, m.sampler, dr);
             V3 wi = (sp.x * u + sp.y * v) + sp.z * wr;
             if (dot(h.n, wi) < 0.0) wi = ((-sp.x) * u - sp.y * v) + sp.z * wr;
-            const double lobe = rt_pow<!TREES>(dot(wr, wi), m.reflect_exp);
+            const double lobe = rt_pow<POW_CALL>(dot(wr, wi), m.reflect_exp);
             double pdf = lobe * dot(h.n, wi);
             V3 fr;
             if (pdf == 0) { fr = v3(0, 0, 0); pdf = 1; }
             else fr = ld3(m.reflect) * lobe;
             W = W * ((fr * dot(h.n, wi)) / pdf);
+            RT_BOUNCE(fr, dot(h.n, wi), pdf, true);
             ray.o = h.p;
             ray.d = wi;
         } else if (EXT && m.kind == RTAMD_TRANSPARENT) {
@@ -2379,6 +2430,9 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
             alive = false;
         }
     }
+    sum.finish(L);
+#undef RT_ADD
+#undef RT_BOUNCE
     return L;
 }
 

@@ -157,15 +157,39 @@ __device__ __forceinline__ bool tile_ray(const rtamd_scene_desc& S, const Launch
     return true;
 }
 
-// EXT instantiations serve scenes with two-child materials (Transparent, Dielectric) or
-// textured ones (SV_Matte); they keep a per-lane list of waiting child rays in private
-// memory and a texture colour across the shadow queries, which the other instantiations
-// do not pay for.
-// TREES = false instantiations serve scenes without a kd-tree (analytic primitives only):
-// no traversal code, no LDS stack, and the registers go to the shading loop.
-template <int MODE, int COUNT, bool EXT, bool TREES, bool AREA_ONLY = false, bool TINY_OK = true, bool NO_BOUNCE = false,
-          bool FUSED = false>
-__global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
+// The builds of trace_kernel.  Every build renders the same frames; which one a launch takes depends on what the
+// library has read from the scene's tables (launch() below).
+//   K_ANALYTIC     scenes without a kd-tree (analytic primitives only): no traversal code, no LDS stack, and the
+//                  registers go to the shading loop
+//   K_TREES        any scene with kd-trees: the general bounce loop
+//   K_EXT          scenes with two-child materials (Transparent, Dielectric) or textured ones (SV_Matte): a per-lane
+//                  list of waiting child rays in private memory and a texture colour held across the shadow queries
+//   K_AREA_TINY / K_AREA / K_AREA_FUSED
+//                  whole frames (accumulators only) of a scene with one kd-tree object and one light under the
+//                  AreaLightTracer, which never bounces: straight-line code.  _TINY serves trees of a few levels
+//                  (single lanes scan the leaves of every kind of ray); the others leave that code out; _FUSED also
+//                  leaves out the general shadow path where the host has shown that no wave takes it
+//   K_STRAIGHT / K_STRAIGHT_ONE
+//                  whole frames of kd scenes under the plain tracer whose materials spawn no child rays (Matte, Phong,
+//                  Emissive): straight-line code as well; _ONE for one kd-tree object of more than a few levels and one
+//                  light (shadow tests ask the tree last, the light loop is one pass, no scans by single lanes)
+//   K_PATH         whole frames under the PathTracer: the closest-hit query and the lobe sample, no direct lighting
+enum { K_ANALYTIC = 0, K_TREES, K_EXT, K_AREA_TINY, K_AREA, K_AREA_FUSED, K_STRAIGHT, K_STRAIGHT_ONE, K_PATH };
+template <int KIND> struct Kind {
+    static constexpr bool ext = KIND == K_EXT;
+    static constexpr bool trees = KIND != K_ANALYTIC;
+    static constexpr bool area_only = KIND == K_AREA_TINY || KIND == K_AREA || KIND == K_AREA_FUSED;
+    static constexpr bool tiny_ok = KIND != K_AREA && KIND != K_AREA_FUSED && KIND != K_STRAIGHT_ONE;
+    static constexpr bool no_bounce = KIND == K_STRAIGHT || KIND == K_STRAIGHT_ONE;
+    static constexpr bool fused = KIND == K_AREA_FUSED;
+    static constexpr bool path = KIND == K_PATH;
+    static constexpr bool one_tree = area_only || KIND == K_STRAIGHT_ONE;
+    static constexpr bool sums_only = area_only || no_bounce || path;       // no per-sample outputs
+};
+template <int MODE, int COUNT, int KIND>
+__global__ __launch_bounds__(BLOCK, Kind<KIND>::trees ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
+    typedef Kind<KIND> K;
+    constexpr bool TREES = K::trees;
     // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
     // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
     // work list is cut into RT_XCD_SEGMENTS contiguous segments and segment j is given to
@@ -222,15 +246,16 @@ __global__ __launch_bounds__(BLOCK, TREES ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC
         stk.node = stack_node;
         stk.t = stack_t;
         stk.slot = stack_slot;
-        stk.tiny_ok = TINY_OK;
+        stk.tiny_ok = K::tiny_ok;
         // (the benchmark's kernel keeps to the code its frame runs: its lights lie outside the tree's box)
-        stk.prefilter_ok = !(AREA_ONLY && !TINY_OK);
-        stk.fused_always = FUSED;
+        stk.prefilter_ok = !(K::area_only && !K::tiny_ok);
+        stk.fused_always = K::fused;
         NoFeed no_feed;
-        const V3 c = trace_wave<COUNT, EXT, TREES, AREA_ONLY, NoFeed, NO_BOUNCE>(S, stk, live, ray, A.depth0, dr, work, first, no_feed);
+        const V3 c = trace_wave<COUNT, K::ext, TREES, K::area_only, NoFeed, K::no_bounce, K::path, K::one_tree>(
+            S, stk, live, ray, A.depth0, dr, work, first, no_feed);
         if (live) {
             const int32_t r8 = quantise(c.x), g8 = quantise(c.y), b8 = quantise(c.z);
-            if (!AREA_ONLY && !NO_BOUNCE) {
+            if (!K::sums_only) {
             if (A.out.rgb) { A.out.rgb[3 * ko] = c.x; A.out.rgb[3 * ko + 1] = c.y; A.out.rgb[3 * ko + 2] = c.z; }
             if (A.out.rgb8) { A.out.rgb8[3 * ko] = r8; A.out.rgb8[3 * ko + 1] = g8; A.out.rgb8[3 * ko + 2] = b8; }
             if (A.out.hit_object) A.out.hit_object[ko] = first.object;
@@ -359,6 +384,10 @@ struct TileFeed {
 // 64-sample groups of the tile work list (all of one tile: A.refill divides the samples per
 // pixel), starts on the first and refills lanes from the others (TileFeed).  Sums per pixel are
 // kept in LDS and added to the accumulators once per pixel, channel and wave.
+// (Scenes with a kd-tree do not refill, not even trees of a few levels under the path tracer, where single lanes
+// scan the leaves of every ray and a refilled primary ray loses nothing: the path-traced Cornell box took 4.42 ms
+// against 3.40 ms with one sample per lane.  Of its lanes 0.73 hold a live path per pass; what a pass costs there is
+// set by how far the wave's walks diverge, and rays of different pixels and depths in one wave diverge more.)
 template <int COUNT>
 __global__ __launch_bounds__(BLOCK, RT_MIN_WAVES_ANALYTIC) void refill_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     __shared__ unsigned long long bins[192];
@@ -446,10 +475,22 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_t
     if (count && executed) return fail(RTAMD_EINVAL, "RTAMD_COUNT_WORK and RTAMD_COUNT_EXECUTED exclude each other%s");
     if (executed && !A.counters) return fail(RTAMD_EINVAL, "RTAMD_COUNT_EXECUTED needs a counter block%s");
     const dim3 grid((unsigned)blocks), block(BLOCK);
+    // whole frames, accumulators only, have builds of their own where the scene allows (see Kind)
+    const bool sums_only = MODE == MODE_TILES && !A.out.rgb && !A.out.rgb8 && !A.out.hit_object && !A.out.hit_prim &&
+                           !A.out.hit_t && !A.out.n_rays;
+    const bool tiny_trees = max_tree_depth < RT_TINY_DEPTH;
+    const bool one_tree_one_light = tree_objects == 1 && S.n_lights == 1;
+    bool area_only = false, no_bounce = false, path = false;
+#ifndef RT_NO_AREA_ONLY
+    area_only = sums_only && !extended && trees && S.tracer_kind == RTAMD_TRACER_AREA && one_tree_one_light;
+#endif
+#ifndef RT_NO_STRAIGHT
+    no_bounce = sums_only && !extended && trees && !area_only && !bounces && S.tracer_kind == RTAMD_TRACER_SHADE && !count && !executed;
+    path = sums_only && !extended && trees && S.tracer_kind == RTAMD_TRACER_PATH && !count && !executed;
+#endif
 #if !defined(RT_NO_REFILL) && !defined(RT_ONLY_HOT)
-    // whole frames of scenes without a kd-tree, accumulators only: waves that refill their lanes
-    if (MODE == MODE_TILES && !trees && !extended && !count && !executed && !A.out.rgb && !A.out.rgb8 && !A.out.hit_object &&
-        !A.out.hit_prim && !A.out.hit_t && !A.out.n_rays) {
+    // waves that refill their lanes: whole frames of scenes without a kd-tree
+    if (sums_only && !extended && !count && !executed && !trees) {
         A.refill = 0;
         for (int r = RT_REFILL_MAX; r > 1; --r)
             if (A.n_samples % r == 0) { A.refill = r; break; }
@@ -462,59 +503,49 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_t
         }
     }
 #endif
-    // the whole-frame case of a single tree under the AreaLightTracer with a single light has a kernel of its
-    // own, in two builds: one for trees of a few levels (lanes scan their own leaves, kd_query_wave), one
-    // without that code for all others
-    const bool tiny_trees = max_tree_depth < RT_TINY_DEPTH;
-    bool area_only = false;
-#ifndef RT_NO_AREA_ONLY
-    area_only = MODE == MODE_TILES && !extended && trees && S.tracer_kind == RTAMD_TRACER_AREA && tree_objects == 1 &&
-                S.n_lights == 1 && !A.out.rgb && !A.out.rgb8 && !A.out.hit_object && !A.out.hit_prim && !A.out.hit_t &&
-                !A.out.n_rays;
-#endif
-    // whole frames, accumulators only, of kd scenes whose materials spawn no child rays under the plain
-    // tracer (Matte / Phong / Emissive: the reference's dragon and teapot scenes as shipped): a build of
-    // the kernel that leaves the bounce loop after one pass, like the area-light kernel
-    bool no_bounce = false;
-#ifndef RT_NO_STRAIGHT
-    no_bounce = MODE == MODE_TILES && !extended && trees && !area_only && !bounces && S.tracer_kind == RTAMD_TRACER_SHADE &&
-                !count && !executed && !A.out.rgb && !A.out.rgb8 && !A.out.hit_object && !A.out.hit_prim && !A.out.hit_t && !A.out.n_rays;
-#endif
+#define RT_LAUNCH(COUNT_, KIND_) hipLaunchKernelGGL((trace_kernel<MODE, COUNT_, KIND_>), grid, block, 0, st, S, A)
+#define RT_LAUNCH_TILES(COUNT_, KIND_) hipLaunchKernelGGL((trace_kernel<MODE_TILES, COUNT_, KIND_>), grid, block, 0, st, S, A)
 #ifdef RT_ONLY_HOT
     // experiment builds (tools/variant_bench.sh): only the whole-frame kernel of the benchmark scene
-    if (area_only && !count && !executed && fused_always) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false, false, true>), grid, block, 0, st, S, A);
-    else if (area_only && !count && !executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
+    if (area_only && !count && !executed && fused_always) RT_LAUNCH_TILES(0, K_AREA_FUSED);
+    else if (area_only && !count && !executed) RT_LAUNCH_TILES(0, K_AREA);
     else return fail(RTAMD_EUNSUPPORTED, "this build holds the whole-frame area-light kernel only%s");
 #elif defined(RT_ONLY_TILES)
     // experiment builds: the uncounted whole-frame kernels only
     if (MODE != MODE_TILES || count || executed) return fail(RTAMD_EUNSUPPORTED, "this build holds the uncounted tile kernels only%s");
-    if (extended) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, true, true>), grid, block, 0, st, S, A);
-    else if (area_only && !tiny_trees && fused_always) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false, false, true>), grid, block, 0, st, S, A);
-    else if (area_only && !tiny_trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
-    else if (area_only) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
-    else if (no_bounce) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, false, true, true>), grid, block, 0, st, S, A);
-    else if (trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true>), grid, block, 0, st, S, A);
-    else hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, false>), grid, block, 0, st, S, A);
+    if (extended) RT_LAUNCH_TILES(0, K_EXT);
+    else if (area_only && !tiny_trees && fused_always) RT_LAUNCH_TILES(0, K_AREA_FUSED);
+    else if (area_only && !tiny_trees) RT_LAUNCH_TILES(0, K_AREA);
+    else if (area_only) RT_LAUNCH_TILES(0, K_AREA_TINY);
+    else if (no_bounce && one_tree_one_light && !tiny_trees) RT_LAUNCH_TILES(0, K_STRAIGHT_ONE);
+    else if (no_bounce) RT_LAUNCH_TILES(0, K_STRAIGHT);
+    else if (path) RT_LAUNCH_TILES(0, K_PATH);
+    else if (trees) RT_LAUNCH_TILES(0, K_TREES);
+    else RT_LAUNCH_TILES(0, K_ANALYTIC);
 #else
     if (extended) {
-        if (count) hipLaunchKernelGGL((trace_kernel<MODE, 1, true, true>), grid, block, 0, st, S, A);
-        else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, true, true>), grid, block, 0, st, S, A);
-        else hipLaunchKernelGGL((trace_kernel<MODE, 0, true, true>), grid, block, 0, st, S, A);
+        if (count) RT_LAUNCH(1, K_EXT);
+        else if (executed) RT_LAUNCH(2, K_EXT);
+        else RT_LAUNCH(0, K_EXT);
     } else if (trees) {
-        if (count) hipLaunchKernelGGL((trace_kernel<MODE, 1, false, true>), grid, block, 0, st, S, A);
-        else if (area_only && executed) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 2, false, true, true>), grid, block, 0, st, S, A);
-        else if (area_only && !tiny_trees && fused_always) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false, false, true>), grid, block, 0, st, S, A);
-        else if (area_only && !tiny_trees) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true, false>), grid, block, 0, st, S, A);
-        else if (area_only) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, true>), grid, block, 0, st, S, A);
-        else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, false, true>), grid, block, 0, st, S, A);
-        else if (no_bounce) hipLaunchKernelGGL((trace_kernel<MODE_TILES, 0, false, true, false, true, true>), grid, block, 0, st, S, A);
-        else hipLaunchKernelGGL((trace_kernel<MODE, 0, false, true>), grid, block, 0, st, S, A);
+        if (count) RT_LAUNCH(1, K_TREES);
+        else if (area_only && executed) RT_LAUNCH_TILES(2, K_AREA_TINY);
+        else if (area_only && !tiny_trees && fused_always) RT_LAUNCH_TILES(0, K_AREA_FUSED);
+        else if (area_only && !tiny_trees) RT_LAUNCH_TILES(0, K_AREA);
+        else if (area_only) RT_LAUNCH_TILES(0, K_AREA_TINY);
+        else if (executed) RT_LAUNCH(2, K_TREES);
+        else if (no_bounce && one_tree_one_light && !tiny_trees) RT_LAUNCH_TILES(0, K_STRAIGHT_ONE);
+        else if (no_bounce) RT_LAUNCH_TILES(0, K_STRAIGHT);
+        else if (path) RT_LAUNCH_TILES(0, K_PATH);
+        else RT_LAUNCH(0, K_TREES);
     } else {
-        if (count) hipLaunchKernelGGL((trace_kernel<MODE, 1, false, false>), grid, block, 0, st, S, A);
-        else if (executed) hipLaunchKernelGGL((trace_kernel<MODE, 2, false, false>), grid, block, 0, st, S, A);
-        else hipLaunchKernelGGL((trace_kernel<MODE, 0, false, false>), grid, block, 0, st, S, A);
+        if (count) RT_LAUNCH(1, K_ANALYTIC);
+        else if (executed) RT_LAUNCH(2, K_ANALYTIC);
+        else RT_LAUNCH(0, K_ANALYTIC);
     }
 #endif
+#undef RT_LAUNCH
+#undef RT_LAUNCH_TILES
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return RTAMD_OK;
@@ -736,7 +767,7 @@ static int scene_create(const rtamd_scene_desc* d, rtamd_scene** out) {
     }
     for (int i = 0; i < d->n_trees; ++i) {
         const rtamd_tree& t = trees[i];
-        if (t.depth + 2 > STACK_MAX) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "kd-tree deeper than the traversal stack%s"); }
+        if (t.depth + 2 > STACK_MAX || t.walk_depth + 2 > STACK_MAX) { rtamd_scene_destroy(s); return fail(RTAMD_EUNSUPPORTED, "kd-tree deeper than the traversal stack%s"); }
         if (t.node_offset < 0 || t.node_offset >= d->n_kd_nodes) { rtamd_scene_destroy(s); return fail(RTAMD_EINVAL, "tree root outside kd_nodes%s"); }
         if (t.shadow_root < 0 || t.shadow_root >= d->n_kd_nodes) { rtamd_scene_destroy(s); return fail(RTAMD_EINVAL, "shadow tree root outside kd_nodes%s"); }
         if (t.depth > s->max_tree_depth) s->max_tree_depth = t.depth;

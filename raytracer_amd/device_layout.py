@@ -33,6 +33,8 @@ CELL = 8
 GROUP = 4           # chunks per group box in `chunk_tree`
 PAD = 1.0e-9
 SHADOW_SUBTREES = not os.environ.get("RTAMD_NO_SHADOW_SUBTREES")
+# shadow trees split triangles at the planes (rt_shadowtree.cpp) rather than their boxes
+PERFECT_SPLITS = not os.environ.get("RTAMD_BOX_SPLITS")
 
 
 def _padded(lo, hi):
@@ -61,29 +63,35 @@ def _morton_order(centroids):
 SHADOW_TREE_SLACK = 4.0e-5        # see shadow_tree_wave in csrc/rt_device.h
 SHADOW_TREE_MIN_ROWS = 512      # trees with at least this many rows get a shadow tree of their own
 AUX_MIN_ROWS = CHUNK  # leaves of more rows than this get a shadow subtree
-AUX_LEAF = 16       # rows at which a shadow subtree stops splitting
+AUX_LEAF = int(os.environ.get('RTAMD_SWEEP_LEAF', 16))       # rows at which a shadow subtree stops splitting
 AUX_MAX_LEAF = 64   # a shadow subtree whose build leaves more rows than this in a leaf is dropped
-AUX_STEP_COST = 1.0  # cost of a traversal step in triangle tests
+AUX_STEP_COST = float(os.environ.get('RTAMD_SWEEP_STEP', 1.0))  # cost of a traversal step in triangle tests
 AUX_DEPTH = 16      # levels a shadow subtree may have (fewer below a deep leaf)
 
 
-def _shadow_subtree(lo, hi, max_depth):
+def _shadow_subtree(lo, hi, max_depth, corners=None, slack=0.0):
     """A kd-tree over the (padded) triangle boxes lo, hi [n, 3], for queries that any hit
     decides (rtamd_shadow_tree_build in csrc/rt_shadowtree.cpp: surface-area heuristic over the
-    box faces, triangles whose box straddles a plane go to both sides).  Returns (axis, split,
-    link, leaf_offset, leaf_row, levels): nodes in preorder, axis -1 for a leaf whose number is
-    link, else link = index of the right child; leaf k holds rows leaf_row[leaf_offset[k] :
-    leaf_offset[k + 1]] (numbers into lo / hi).  None when some leaf would keep more than
-    AUX_MAX_LEAF rows within max_depth levels."""
+    box faces, triangles whose box straddles a plane go to both sides - or, with the triangles'
+    `corners` [n, 9] and the absolute `slack` the boxes were widened by, only to the sides the
+    triangle itself comes within the slack of).  Returns (axis, split, link, leaf_offset,
+    leaf_row, leaf_box, levels): nodes in preorder, axis -1 for a leaf whose number is link, else
+    link = index of the right child; leaf k holds rows leaf_row[leaf_offset[k] :
+    leaf_offset[k + 1]] (numbers into lo / hi) inside leaf_box[k] (lo.xyz, hi.xyz).  None when
+    some leaf would keep more than AUX_MAX_LEAF rows within max_depth levels."""
     lib = capi.library()
     lo = numpy.ascontiguousarray(lo, dtype=numpy.float64)
     hi = numpy.ascontiguousarray(hi, dtype=numpy.float64)
+    if corners is not None:
+        corners = numpy.ascontiguousarray(corners, dtype=numpy.float64)
+        assert corners.shape == (len(lo), 9)
     n_nodes, n_leaves, n_rows, levels = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
 
-    def call(axis, split, link, offsets, rows, max_nodes, max_rows):
+    def call(axis, split, link, offsets, rows, boxes, max_nodes, max_rows):
         return lib.rtamd_shadow_tree_build(
             lo.ctypes.data, hi.ctypes.data, len(lo), int(max_depth), AUX_LEAF, AUX_MAX_LEAF, AUX_STEP_COST,
-            axis, split, link, max_nodes, offsets, rows, max_rows,
+            corners.ctypes.data if corners is not None else None, float(slack),
+            axis, split, link, max_nodes, offsets, rows, boxes, max_rows,
             C.byref(n_nodes), C.byref(n_leaves), C.byref(n_rows), C.byref(levels))
 
     max_nodes, max_rows = 2 * len(lo) + 64, 6 * len(lo) + 1024           # usually enough; the sizes come back either way
@@ -93,8 +101,9 @@ def _shadow_subtree(lo, hi, max_depth):
         link = numpy.empty(max_nodes, dtype=numpy.int32)
         offsets = numpy.empty(max_nodes + 1, dtype=numpy.int64)
         rows = numpy.empty(max_rows, dtype=numpy.int32)
+        boxes = numpy.zeros((max_nodes, 6), dtype=numpy.float64)
         status = call(axis.ctypes.data, split.ctypes.data, link.ctypes.data, offsets.ctypes.data, rows.ctypes.data,
-                      max_nodes, max_rows)
+                      boxes.ctypes.data, max_nodes, max_rows)
         if status == capi.EUNSUPPORTED:
             return None
         if status == 0:
@@ -106,12 +115,12 @@ def _shadow_subtree(lo, hi, max_depth):
         raise RuntimeError("rtamd_shadow_tree_build failed (%d)" % status)
     axis, split, link = axis[:n_nodes.value], split[:n_nodes.value], link[:n_nodes.value]
     offsets = offsets[:n_leaves.value + 1]
-    return axis, split, link, offsets, rows[:n_rows.value], int(levels.value)
+    return axis, split, link, offsets, rows[:n_rows.value], boxes[:n_leaves.value], int(levels.value)
 
 
 def device_arrays(flat):
     """Tables to upload (see _device_arrays), worked out once per flat scene."""
-    key = (SHADOW_SUBTREES, SHADOW_TREE_MIN_ROWS)
+    key = (SHADOW_SUBTREES, SHADOW_TREE_MIN_ROWS, PERFECT_SPLITS)
     cached = getattr(flat, "_device_arrays", None)
     if cached is None or cached[0] != key:
         cached = flat._device_arrays = (key,) + _device_arrays(flat)
@@ -230,13 +239,16 @@ def _device_arrays(flat):
             g = geom[:, src_rows]
             v0, v1, v2 = g[0:3].T, (g[0:3] + g[3:6]).T, (g[0:3] + g[6:9]).T
             blo, bhi = _padded(numpy.minimum(numpy.minimum(v0, v1), v2), numpy.maximum(numpy.maximum(v0, v1), v2))
+            reach = max(float(numpy.abs(blo).max()), float(numpy.abs(bhi).max()), 1e-30)
+            wide = PAD * (1.0 + reach)              # what _padded added at the least
             if slack:
-                wide = slack * max(float(numpy.abs(blo).max()), float(numpy.abs(bhi).max()), 1e-30)
+                wide = slack * reach
                 blo, bhi = blo - wide, bhi + wide
-            built = _shadow_subtree(blo, bhi, room)
+            corners = numpy.concatenate([v0, v1, v2], axis=1) if PERFECT_SPLITS else None
+            built = _shadow_subtree(blo, bhi, room, corners, wide)
             if built is None:
                 return None
-            axis, split, link, offsets, rows_of, levels = built
+            axis, split, link, offsets, rows_of, leaf_box, levels = built
             root = next_node[0]
             more = numpy.zeros(len(axis), dtype=nodes.dtype)
             is_leaf = axis < 0
@@ -249,8 +261,8 @@ def _device_arrays(flat):
             boxes32 = numpy.zeros((len(axis), 8), dtype=numpy.float32)
             filled = numpy.nonzero(numpy.diff(offsets) > 0)[0]                     # leaves that hold rows
             if len(filled):
-                leaf_lo = numpy.minimum.reduceat(blo[rows_of], offsets[:-1][filled], axis=0)
-                leaf_hi = numpy.maximum.reduceat(bhi[rows_of], offsets[:-1][filled], axis=0)
+                # (the builder's own boxes: around the parts of the triangles inside the leaf's cell)
+                leaf_lo, leaf_hi = leaf_box[filled, 0:3], leaf_box[filled, 3:6]
                 node_of_leaf = numpy.nonzero(is_leaf)[0][numpy.argsort(link[is_leaf])]
                 l32, h32 = _boxes_f32(leaf_lo, leaf_hi)
                 boxes32[node_of_leaf[filled], 0:3], boxes32[node_of_leaf[filled], 3:6] = l32, h32
@@ -276,7 +288,7 @@ def _device_arrays(flat):
             got = attach(lo_r + firsts, capi.MAX_TREE_DEPTH, SHADOW_TREE_SLACK)
             if got is not None:
                 t.shadow_root = got[0]
-                t.depth = max(t.depth, got[1])
+                t.walk_depth = max(t.walk_depth, got[1])
                 whole.add(ti)
         for node, count in zip(big, counts[counts > AUX_MIN_ROWS]):
             tree = int(numpy.searchsorted(tree_starts, node, side="right")) - 1
@@ -288,7 +300,7 @@ def _device_arrays(flat):
             if got is None:
                 continue
             # what a walk may now pass through
-            tree_recs[tree].depth = max(tree_recs[tree].depth, int(level[node]) + got[1])
+            tree_recs[tree].walk_depth = max(tree_recs[tree].walk_depth, int(level[node]) + got[1])
             la32[node, 6] = numpy.array([got[0]], dtype=numpy.int32).view(numpy.float32)[0]
         if extra_nodes:
             nodes = numpy.concatenate([nodes] + extra_nodes)

@@ -158,6 +158,7 @@ class _Flattener(object):
         _fill(t.bbox_hi, (bb.x1, bb.y1, bb.z1))
         t.node_offset, t.ref_offset, t.prim_offset = self.n_nodes, self.n_refs, self.n_prims
         t.smooth, t.depth = int(smooth), st["depth"]
+        t.walk_depth = st["depth"]
 
         # per-primitive tables
         v0 = numpy.array([b.obj.v0 for b in boxes], dtype=numpy.float64).reshape(-1, 3)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off sweep over more worlds of the random families than the test suite renders:
   python tests/fuzz_sweep.py FIRST LAST [MESH_FIRST MESH_LAST]
+  python tests/fuzz_sweep.py --worlds fuzz_232,fuzzmesh_42,...
 Every world goes through tests/test_gpu_parity.check_tiles_against_oracle (whole frames, every sample, ids /
 ray counts / reference work exact, the timed and both counting kernels the same frame).  Needs a GPU."""
 import os
@@ -20,10 +21,14 @@ def main():
     World(viewmode="parallel", buildfunction="fuzz_0", seed=1)       # loads the scene files
     import test_gpu_parity as t
     fuzz = [m for name, m in sys.modules.items() if name.startswith("rtamd_scene_fuzz")][0]
-    a = [int(x) for x in sys.argv[1:]]
-    jobs = [("fuzz_%d", fuzz._make, k) for k in range(a[0], a[1])]
-    if len(a) > 2:
-        jobs += [("fuzzmesh_%d", fuzz._make_mesh, k) for k in range(a[2], a[3])]
+    if sys.argv[1] == "--worlds":
+        jobs = [("fuzz_%d", fuzz._make, int(n.split("_")[1])) if n.startswith("fuzz_") else ("fuzzmesh_%d", fuzz._make_mesh, int(n.split("_")[1]))
+                for n in sys.argv[2].split(",")]
+    else:
+        a = [int(x) for x in sys.argv[1:]]
+        jobs = [("fuzz_%d", fuzz._make, k) for k in range(a[0], a[1])]
+        if len(a) > 2:
+            jobs += [("fuzzmesh_%d", fuzz._make_mesh, k) for k in range(a[2], a[3])]
     bad = 0
     for pattern, make, k in jobs:
         name = pattern % k

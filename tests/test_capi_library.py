@@ -59,12 +59,14 @@ def test_shadow_tree_builder_on_the_host():
     hi = lo + rng.uniform(0.01, 0.3, (500, 3))
     n_nodes, n_leaves, n_rows, depth = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
 
-    def call(lo, hi, max_depth, leaf, max_leaf, out=None):
-        args = [None] * 3 + [0] + [None] * 2 + [0]
+    def call(lo, hi, max_depth, leaf, max_leaf, out=None, corners=None, slack=0.0, boxes=None):
+        args = [None] * 3 + [0] + [None] * 3 + [0]
         if out is not None:
             axis, split, link, offsets, rows = out
-            args = [axis.ctypes.data, split.ctypes.data, link.ctypes.data, len(axis), offsets.ctypes.data, rows.ctypes.data, len(rows)]
-        return lib.rtamd_shadow_tree_build(lo.ctypes.data, hi.ctypes.data, len(lo), max_depth, leaf, max_leaf, 1.0, *args,
+            args = [axis.ctypes.data, split.ctypes.data, link.ctypes.data, len(axis), offsets.ctypes.data, rows.ctypes.data,
+                    boxes.ctypes.data if boxes is not None else None, len(rows)]
+        return lib.rtamd_shadow_tree_build(lo.ctypes.data, hi.ctypes.data, len(lo), max_depth, leaf, max_leaf, 1.0,
+                                           corners.ctypes.data if corners is not None else None, slack, *args,
                                            C.byref(n_nodes), C.byref(n_leaves), C.byref(n_rows), C.byref(depth))
     assert call(lo, hi, 30, 8, 64) == 0                                   # sizes only
     sizes = (n_nodes.value, n_leaves.value, n_rows.value, depth.value)
@@ -96,3 +98,50 @@ def test_shadow_tree_builder_on_the_host():
     assert call(same_lo, same_hi, 30, 8, 64) == capi.EUNSUPPORTED
     assert call(same_lo, same_hi, 30, 8, 128) == 0 and (n_nodes.value, n_leaves.value, n_rows.value) == (1, 1, 100)
     assert call(lo, hi, 30, 0, 64) == -1 and call(lo, hi, -1, 8, 64) == -1 and call(lo, hi, 30, 16, 8) == -1
+
+
+def test_shadow_tree_builder_splits_triangles_at_the_planes():
+    """With the triangles' corners the builder lists a triangle only where the triangle itself comes within the
+    slack of a leaf's cell - and everywhere it does: sample points of every triangle, moved by up to the slack,
+    always find their triangle in the leaf whose cell they fall into, inside that leaf's box."""
+    import ctypes as C
+    import numpy
+    from raytracer_amd import capi
+    lib = capi.library()
+    rng = numpy.random.RandomState(11)
+    n = 400
+    centre = rng.uniform(-1, 1, (n, 3))
+    corners = numpy.ascontiguousarray(numpy.concatenate([centre + rng.uniform(-0.25, 0.25, (n, 3)) for _ in range(3)], axis=1))
+    tri = corners.reshape(n, 3, 3)
+    slack = 1e-3
+    lo = numpy.ascontiguousarray(tri.min(axis=1) - slack)
+    hi = numpy.ascontiguousarray(tri.max(axis=1) + slack)
+    n_nodes, n_leaves, n_rows, depth = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+
+    def build(with_corners):
+        cap = 64 * n
+        axis, split, link = numpy.zeros(cap, numpy.int32), numpy.zeros(cap), numpy.zeros(cap, numpy.int32)
+        offsets, rows, boxes = numpy.zeros(cap + 1, numpy.int64), numpy.zeros(cap, numpy.int32), numpy.zeros((cap, 6))
+        rc = lib.rtamd_shadow_tree_build(lo.ctypes.data, hi.ctypes.data, n, 30, 4, 64, 1.0,
+                                         corners.ctypes.data if with_corners else None, slack,
+                                         axis.ctypes.data, split.ctypes.data, link.ctypes.data, cap, offsets.ctypes.data,
+                                         rows.ctypes.data, boxes.ctypes.data, cap,
+                                         C.byref(n_nodes), C.byref(n_leaves), C.byref(n_rows), C.byref(depth))
+        assert rc == 0
+        return axis, split, link, offsets, rows, boxes, n_rows.value
+    plain = build(False)
+    axis, split, link, offsets, rows, boxes, total = build(True)
+    assert total < plain[6]                              # thin slanted triangles: their boxes reach much farther than they do
+
+    def leaf_of(p):
+        at = 0
+        while axis[at] >= 0:
+            at = at + 1 if p[axis[at]] < split[at] else int(link[at])
+        return int(link[at])
+    for t in range(n):
+        w = rng.dirichlet((1, 1, 1), 12)
+        points = w.dot(tri[t]) + rng.uniform(-0.9 * slack, 0.9 * slack, (12, 3))
+        for p in points:
+            k = leaf_of(p)
+            assert t in rows[offsets[k]:offsets[k + 1]]
+            assert (boxes[k, 0:3] <= p).all() and (p <= boxes[k, 3:6]).all()
