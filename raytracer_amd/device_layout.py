@@ -63,9 +63,9 @@ def _morton_order(centroids):
 SHADOW_TREE_SLACK = 4.0e-5        # see shadow_tree_wave in csrc/rt_device.h
 SHADOW_TREE_MIN_ROWS = 512      # trees with at least this many rows get a shadow tree of their own
 AUX_MIN_ROWS = CHUNK  # leaves of more rows than this get a shadow subtree
-AUX_LEAF = int(os.environ.get('RTAMD_SWEEP_LEAF', 16))       # rows at which a shadow subtree stops splitting
+AUX_LEAF = 16       # rows at which a shadow subtree stops splitting
 AUX_MAX_LEAF = 64   # a shadow subtree whose build leaves more rows than this in a leaf is dropped
-AUX_STEP_COST = float(os.environ.get('RTAMD_SWEEP_STEP', 1.0))  # cost of a traversal step in triangle tests
+AUX_STEP_COST = 1.0  # cost of a traversal step in triangle tests
 AUX_DEPTH = 16      # levels a shadow subtree may have (fewer below a deep leaf)
 
 
