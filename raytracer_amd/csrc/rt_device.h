@@ -4,6 +4,20 @@
 // /root/reference).  Comparisons are written in the reference's own form and order
 // (`not t > eps`, strict `<`, Python's min/max argument rules) because NaN and
 // infinities from zero direction components flow through them.
+//
+// Compile-time switches of this file and rt_kernels.hip (all off / at their defaults in the product library):
+//
+//   builds that check or measure (tools/, tests/fuzz_sweep.py; never shipped)
+//     RT_PHASE_TIMERS       shader-clock timers and walk statistics per part of a kd query (tools/phase_profile.py)
+//     RT_REF_ORDER          a path's radiance summed in the reference's order (PathSum below)
+//     RT_TRI_LU             triangle systems solved by LU with pivoting, as numpy.linalg.solve does (tri_solve_v)
+//     RT_POW_ALT            another evaluation of pow (rt_pow)
+//     RT_ONLY_HOT / RT_ONLY_TILES   libraries that hold only the benchmark's kernel / only the whole-frame kernels, for
+//                           quick experiment builds (tools/build_variant.sh); RT_NO_REFILL: no refilled waves
+//   tunables, each with the measurements that set its default next to its definition
+//     RT_STACK_MAX (40), RT_LDS_STACK (10), RT_TINY_DEPTH (8), RT_MAX_SKIPS (1), RT_MAX_LOADS (3),
+//     RT_ST_MAX_SKIPS (1), RT_ST_MAX_LOADS (3), RT_STEAL_PASSES (1), RT_STEAL_MIN_PAIRS (1) here;
+//     RT_BLOCK (64), RT_MIN_WAVES (4), RT_MIN_WAVES_ANALYTIC (4), RT_REFILL_MAX (16), RT_GROUP_SHIFT_MAX (4) in rt_kernels.hip
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -239,20 +253,13 @@ __device__ __forceinline__ bool tri_solve_v(V3 v0, V3 e1, V3 e2, const Ray& r,
 #else
 __device__ __forceinline__ bool tri_solve_v(V3 v0, V3 e1, V3 e2, const Ray& r,
                                             double& alpha, double& beta, double& t) {
-#ifdef RT_TRI_FMA
-#pragma clang fp contract(fast)
-#endif
     const V3 pvec = cross(r.d, e2);
     const double det = dot(e1, pvec);
-#ifndef RT_EXACT_DIVIDE
     // reciprocal by two Newton steps on the hardware estimate (within an ulp or so of
     // 1/det; a zero or denormal det gives inf/NaN and with it a miss, as the division does)
     double inv = __builtin_amdgcn_rcp(det);
     inv = fma(inv, fma(-det, inv, 1.0), inv);
     inv = fma(inv, fma(-det, inv, 1.0), inv);
-#else
-    const double inv = 1.0 / det;
-#endif
     const V3 tvec = r.o - v0;
     alpha = dot(tvec, pvec) * inv;
     const V3 qvec = cross(tvec, e1);
@@ -359,10 +366,6 @@ struct KdStack {
     bool prefilter_ok;  // shadow rays that end inside a tree's box may ask the shadow tree first (a
                         // constant false keeps that second copy of the walk out of a kernel)
 };
-#define RT_KD_STACK_LDS_BYTES (LDS_STACK * 64 * 12)
-#ifndef RT_SMALL_LEAF
-#define RT_SMALL_LEAF 0
-#endif
 // Shadow queries keep their rounds short so that lanes do not wait for the one with the
 // longest walk and idle lanes can be handed part of it.  1080p dragon frame: skips 1: 15.95,
 // 2: 16.46, 4: 17.20, 8: 17.79, unbounded 18.03 ms; node loads unbounded 15.97, 4: 15.76,
@@ -389,7 +392,6 @@ struct KdStack {
 #ifndef RT_ST_MAX_LOADS
 #define RT_ST_MAX_LOADS 3
 #endif
-constexpr int SMALL_LEAF = RT_SMALL_LEAF;     // leaves up to this size are scanned by the lane that reached them
 
 // BoundingBox.hit (geometry.py:49-70) on the tree's root box.
 __device__ __forceinline__ bool root_box(const rtamd_tree& T, const Ray& r, double& tmin, double& tmax) {
@@ -985,11 +987,7 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
     // box: 9 nodes) is walked faster without them
     const bool use_leaf_aabb = S.leaf_aabb != nullptr && T.depth >= 8;
     V3 inv_d = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
-#ifndef RT_NO_STEAL
     constexpr bool STEAL = SHADOW && COUNT != 1;
-#else
-    constexpr bool STEAL = false;
-#endif
     // Handing over.  A shadow ray whose every possible hit lies before its limit (no limit,
     // or the ray leaves the root box before it) is occluded exactly when any triangle on it
     // is hit, whichever part of the walk finds it.  Lanes whose own query is answered take
@@ -1002,7 +1000,6 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
     bool out_found = false;
     double out_t = 0;
     bool steal_ok = STEAL && walking && (t_exit * (1.0 + 1e-9) + 1e-9 < limit);
-#ifndef RT_NO_SHADOW_SUBTREES
     // Whether such a ray is occluded does not depend on which leaf lists the triangle it hits:
     // it walks the tree's shadow tree (the same triangles in a kd-tree built for this walk);
     // only rays with a limit inside the tree's box go on below, on the reference's tree
@@ -1016,7 +1013,6 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
             if (fast) { out_found = f2; out_t = b2.t; walking = false; }
         }
         if (!__ballot(walking)) { found = out_found; best.t = out_t; return; }
-#ifndef RT_NO_LIMITED_PREFILTER
         // A ray that ends inside the tree's box (a light among the triangles: the reference's j.py)
         // is answered by the first item in scan order that it hits, wherever on the ray that hit
         // lies - the reference's walk, below.  But when no triangle at all is hit before the limit,
@@ -1032,10 +1028,8 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
             if (limited && !f3) walking = false;
             if (!__ballot(walking)) { found = out_found; best.t = out_t; return; }
         }
-#endif
         steal_ok = false;
     }
-#endif
     PhaseClock clk;
     clk.start(SHADOW ? (limit_in > T_INF ? 36 : 8) : 0);     // shadow queries without a limit (ambient occlusion) apart
     clk.count(PH_QUERIES);
@@ -1175,7 +1169,6 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
                 first = nd.a;
                 count = nd.b >> 2;
                 cbase = S.chunk_boxes ? (int32_t)nd.split : -1;
-#ifndef RT_NO_LEAF_AABB
                 // a leaf whose triangles' box the ray misses holds no hit: the lane walks on at
                 // once (not when counting: the reference tests the rows)
                 if (COUNT != 1 && use_leaf_aabb) {
@@ -1194,7 +1187,6 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
                         if (STEAL && ++skips >= RT_MAX_SKIPS) { parked = true; break; }
                         continue;
                     }
-#ifndef RT_NO_SHADOW_SUBTREES
                     // a query that any hit decides walks on into the leaf's own subtree, if it has
                     // one (the root's index rides in the box row): small leaves with tight boxes
                     // instead of hundreds of rows
@@ -1205,9 +1197,7 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
                             continue;
                         }
                     }
-#endif
                 }
-#endif
                 break;
             }
         }
@@ -1217,7 +1207,7 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
         // rays of one tile that have not bounced yet run close together: their lanes reach
         // the same leaves and read the same rows, so each lane scans its own leaf; rays
         // that have scattered are tested by the wave together (packed and chunk steps below)
-        const bool small = at_leaf && (lane_scans ? cbase < 0 : (count <= SMALL_LEAF || (tiny && cbase < 0)));
+        const bool small = at_leaf && (lane_scans ? cbase < 0 : (count == 0 || (tiny && cbase < 0)));
         if (small) {
             if (SHADOW) {
                 for (int32_t i = 0; i < count; ++i) {
@@ -1268,7 +1258,6 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
         clk.lap(PH_PACK32);
 
         unsigned long long big = __ballot(at_leaf && !small && count > 32);
-#ifndef RT_NO_LANE_BOXED
         if (lane_scans) {
             // boxed leaves as well: each lane scans its own leaf through the cell boxes
             const bool mine = at_leaf && !small && count > 32 && cbase >= 0;
@@ -1282,18 +1271,12 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
                 clk.lap(PH_BIG_BOXES);
             }
         }
-#endif
         // Shadow queries on boxed leaves, first part: every lane tests its own ray against
         // the chunk boxes of its own leaf (lanes of a wave mostly share a few big leaves, so
         // these loads coalesce), leaving a mask of touched chunks.  The rays are then taken
         // one at a time below, with no box step of their own.
-#ifndef RT_NO_BOX_PREPASS
         const bool prepass = SHADOW && S.chunk_tree != nullptr;
         if (prepass && at_leaf && !small && cbase >= 0 && count <= 4096 && !boxes_done) chunk_boxes_of_leaf();
-#else
-        const bool prepass = false;
-#endif
-#ifndef RT_NO_LEAF_SHARING
         // Shadow queries, second part: lanes that stand in the same leaf are served together.
         // For every chunk that any of them touches the wave loads its 64 rows once and tests
         // them against each of those rays in turn (the ray rides in scalar registers).  A
@@ -1367,7 +1350,6 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
             }
             clk.lap(PH_BIG_BOXES);
         }
-#endif
 #ifdef RT_PHASE_TIMERS
         if (SHADOW && prepass) {
             // sharing statistics of boxed leaves: rays, distinct leaves, (ray, chunk) pairs, distinct (leaf, chunk) pairs
@@ -1936,7 +1918,6 @@ __device__ __forceinline__ V3 texture_color(const rtamd_scene_desc& S, int tex, 
 template <int COUNT, bool EXT, bool TREES, bool ONE_TREE = false, bool FUSED_OK = ONE_TREE, bool POW_CALL = !TREES>
 __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const KdStack& stk, bool lit, const rtamd_material& m,
                                 const Hit& h, V3 wo, bool area, V3 tex, Draw& dr, Work<COUNT>& w) {
-#ifndef RT_NO_FUSED_SHADOWS
     if (ONE_TREE && FUSED_OK && COUNT != 1 && !EXT && (stk.fused_always || (S.ambient.kind == RTAMD_AMBIENT_OCCLUDER && S.lights[0].cast_shadow &&
                                                                S.leaf_aabb != nullptr))) {
         // One kd-tree, an ambient occluder and one shadow-casting light: the occlusion ray and
@@ -2057,7 +2038,6 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
             dr = drawn;
         }
     }
-#endif
     // ambient_color.L(sr): AmbientLight (light.py:14-15) or AmbientOccluder (light.py:85-100)
     V3 amb = ld3(S.ambient.radiance);
     if (S.ambient.kind == RTAMD_AMBIENT_OCCLUDER) {
@@ -2154,14 +2134,6 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
 
 struct Primary { int32_t object, prim; double t; };
 
-// A child ray of a Transparent / Dielectric hit that waits while its sibling's subtree is
-// traced: ray, product of the weights down to it, and Dielectric's colour filter, which is
-// raised to the child's own hit distance once that is known (material.py:463-482).
-struct PendingRay {
-    V3 o, d, W, filter;
-    int32_t depth, has_filter;
-};
-
 // Side of the surface a ray arrives on, relative index and the discriminant of Snell's law:
 // PerfectTransmitter (material.py:135-159) and FresnelReflector/Transmitter (:170-223).
 __device__ __forceinline__ bool refraction(const rtamd_material& m, V3 n, V3 d, V3& nf, double& eta,
@@ -2199,39 +2171,85 @@ __device__ __forceinline__ V3 powv(V3 b, double e) { return v3(rt_pow<false>(b.x
 // wave's lanes stay filled while paths of different lengths end at different bounces (the kernels
 // that own a list of samples per wave pass one; NoFeed: a lane traces one sample).
 // How a path's radiance is summed.  The kernels carry the product of the bounce weights forward: L += W * local at
-// every hit, W *= (fr * n.wi) / pdf at every bounce.  The reference's recursion sums from the last hit back to the
-// first, L = local + ((fr * L_child) * n.wi) [/ pdf] (material.py:283-289, :385-394, :402-411): the same factors in
-// another order, which agree to rounding except where a glossy lobe is denormal.  Checking builds (-DRT_REF_ORDER, the
-// plain bounce loop only: no two-child materials, no refilled lanes) keep every level's terms and sum in the
-// reference's order, to tell such samples from real differences.
+// every hit, W *= (fr * n.wi) / pdf at every bounce (a waiting sibling of a two-child material keeps its own W).  The
+// reference's recursion sums from the last hit back to the first, L = local + ((fr * L_child) * n.wi) [/ pdf]
+// (material.py:283-289, :385-394, :402-411, :420-437, :448-483): the same factors in another order, which agree to
+// rounding except where a glossy lobe is denormal.  Checking builds (-DRT_REF_ORDER; not for refilled lanes) keep a
+// frame per level of the recursion - what the level has added itself, and how its value enters its parent's sum - and
+// fold them in the reference's order, to tell such samples from real differences.
 #ifdef RT_REF_ORDER
 #define RT_REF_ORDER_ON true
 #else
 #define RT_REF_ORDER_ON false
 #endif
+// how a child's value V enters its parent's sum (a: colour, s1, s2: scalars, t: the child's own hit distance)
+enum { FOLD_MIRROR = 0,         // + (a * V) * s1                   Reflective.shade, material.py:393
+       FOLD_LOBE,               // + ((a * V) * s1) / s2            GlossyReflective.shade :410, Matte.path_shade :289
+       FOLD_PLAIN,              // + V                              Transparent.shade, total internal reflection :430
+       FOLD_GLASS_MIRROR,       // + (V * s1) * a                   Transparent.shade :434
+       FOLD_SCALED,             // + (s1 * V) * s2                  Transparent.shade :435
+       FOLD_FILTERED,           // + V * a ** t                     Dielectric.shade :460-465
+       FOLD_FRESNEL };          // + ((s1 * V) * a ** t) * s2       Dielectric.shade :477-482
+struct Fold { int kind; V3 a; double s1, s2; };
+__device__ __forceinline__ Fold fold_of(int kind, V3 a, double s1, double s2) { Fold f; f.kind = kind; f.a = a; f.s1 = s1; f.s2 = s2; return f; }
 template <bool REFERENCE_ORDER> struct PathSum {
     __device__ __forceinline__ void add(V3& L, V3 W, V3 x) { L = L + W * x; }
-    __device__ __forceinline__ void bounce(V3, double, double, bool) {}
+    __device__ __forceinline__ void child(const Fold&) {}
+    __device__ __forceinline__ void resume(int, const Fold&) {}
+    __device__ __forceinline__ void hit(double) {}
     __device__ __forceinline__ void finish(V3&) {}
 };
 template <> struct PathSum<true> {
     static constexpr int MAX_LEVELS = 40;
-    V3 local[MAX_LEVELS], fr[MAX_LEVELS];
-    double nd[MAX_LEVELS], pdf[MAX_LEVELS];
-    bool divide[MAX_LEVELS];
-    int n = 0;
-    V3 here = {0, 0, 0};            // what the level the lane stands on has added itself
-    __device__ __forceinline__ void add(V3&, V3, V3 x) { here = here + x; }
-    __device__ __forceinline__ void bounce(V3 f, double ndotwi, double p, bool div) {
-        if (n < MAX_LEVELS) { local[n] = here; fr[n] = f; nd[n] = ndotwi; pdf[n] = p; divide[n] = div; n++; here = v3(0, 0, 0); }
+    V3 here[MAX_LEVELS];            // what each open level has added so far, folded children included
+    Fold how[MAX_LEVELS];           // how the level's value will enter its parent's
+    double t[MAX_LEVELS];           // the level's own hit distance (0 for a miss)
+    int top = 0;
+    __device__ PathSum() { here[0] = v3(0, 0, 0); t[0] = 0; }
+    __device__ __forceinline__ void add(V3&, V3, V3 x) { here[top] = here[top] + x; }
+    __device__ __forceinline__ void hit(double tt) { t[top] = tt; }
+    __device__ __forceinline__ void fold() {
+        const V3 v = here[top];
+        const Fold& f = how[top];
+        const V3 filter = (f.kind == FOLD_FILTERED || f.kind == FOLD_FRESNEL)
+                              ? v3(pow(f.a.x, t[top]), pow(f.a.y, t[top]), pow(f.a.z, t[top])) : v3(1, 1, 1);
+        V3 up;
+        switch (f.kind) {
+        case FOLD_MIRROR: up = (f.a * v) * f.s1; break;
+        case FOLD_LOBE: up = ((f.a * v) * f.s1) / f.s2; break;
+        case FOLD_PLAIN: up = v; break;
+        case FOLD_GLASS_MIRROR: up = (v * f.s1) * f.a; break;
+        case FOLD_SCALED: up = (f.s1 * v) * f.s2; break;
+        case FOLD_FILTERED: up = v * filter; break;
+        default: up = ((f.s1 * v) * filter) * f.s2; break;
+        }
+        top--;
+        here[top] = here[top] + up;
+    }
+    // the level the lane stands on spawns a child and the lane follows it
+    __device__ __forceinline__ void child(const Fold& f) {
+        if (top + 1 < MAX_LEVELS) { top++; here[top] = v3(0, 0, 0); t[top] = 0; how[top] = f; }
+    }
+    // the lane takes up a sibling that waited at `level` (0 = the primary ray): everything deeper is complete
+    __device__ __forceinline__ void resume(int level, const Fold& f) {
+        while (top >= level && top > 0) fold();
+        child(f);
     }
     __device__ __forceinline__ void finish(V3& L) {
-        L = here;
-        for (int k = n - 1; k >= 0; --k) {
-            const V3 up = (fr[k] * L) * nd[k];
-            L = local[k] + (divide[k] ? up / pdf[k] : up);
-        }
+        while (top > 0) fold();
+        L = here[0];
     }
+};
+
+// A child ray of a Transparent / Dielectric hit that waits while its sibling's subtree is
+// traced: ray, product of the weights down to it, and Dielectric's colour filter, which is
+// raised to the child's own hit distance once that is known (material.py:463-482).
+struct PendingRay {
+    V3 o, d, W, filter;
+    int32_t depth, has_filter;
+#ifdef RT_REF_ORDER
+    Fold how;           // checking builds: how the child's value enters its parent's sum (PathSum)
+#endif
 };
 
 struct NoFeed {
@@ -2255,9 +2273,8 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
     // kernels measured faster with it inline
     constexpr bool POW_CALL = !TREES || !AREA_ONLY;
     V3 L = v3(0, 0, 0), W = v3(1, 1, 1);
-    PathSum<RT_REF_ORDER_ON && !EXT && !FEED::on> sum;
+    PathSum<RT_REF_ORDER_ON && !FEED::on> sum;
 #define RT_ADD(X) sum.add(L, W, (X))
-#define RT_BOUNCE(FR, ND, PDF, DIV) sum.bounce((FR), (ND), (PDF), (DIV))
     const int depth0 = depth;
     bool busy = alive;                      // FEED: the lane holds a sample that is not handed in yet
     const int tracer_kind = AREA_ONLY ? (int)RTAMD_TRACER_AREA : PATH_ONLY ? (int)RTAMD_TRACER_PATH : S.tracer_kind;
@@ -2278,6 +2295,9 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
                 ray.o = q.o; ray.d = q.d; W = q.W; filter = q.filter;
                 lane_depth = q.depth; has_filter = q.has_filter != 0;
                 alive = true;
+#ifdef RT_REF_ORDER
+                sum.resume(q.depth - depth0, q.how);
+#endif
             }
             if (alive && !area && lane_depth > S.depth_limit) { RT_ADD(background); alive = false; }
             if (!__ballot(alive || n_pending > 0)) break;
@@ -2305,6 +2325,7 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
         if (alive && !hit) { RT_ADD(background); alive = false; }
         if (alive && primary) { first.object = h.object; first.prim = h.prim; first.t = h.t; }
         primary = false;
+        if (EXT && alive) sum.hit(h.t);
         if (EXT && alive && has_filter) { W = W * powv(filter, h.t); has_filter = false; }
         const rtamd_material& m = S.materials[alive ? h.material : 0];
         const V3 wo = -ray.d;
@@ -2330,7 +2351,7 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
                 const double pdf = dot(h.n, wi) / PI;
                 const double ndotwi = dot(h.n, wi);
                 W = W * ((ld3(m.diffuse) * ndotwi) / pdf);
-                RT_BOUNCE(ld3(m.diffuse), ndotwi, pdf, true);
+                sum.child(fold_of(FOLD_LOBE, ld3(m.diffuse), ndotwi, pdf));
                 ray.o = h.p;
                 ray.d = wi;
             }
@@ -2356,7 +2377,7 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
             const double pdf = dot(h.n, wi);
             const V3 fr = ld3(m.reflect) / pdf;
             W = W * (fr * dot(h.n, wi));
-            RT_BOUNCE(fr, dot(h.n, wi), 1.0, false);
+            sum.child(fold_of(FOLD_MIRROR, fr, dot(h.n, wi), 1.0));
             ray.o = h.p;
             ray.d = wi;
         } else if (m.kind == RTAMD_GLOSSY_REFLECTIVE) {
@@ -2375,7 +2396,7 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
             if (pdf == 0) { fr = v3(0, 0, 0); pdf = 1; }
             else fr = ld3(m.reflect) * lobe;
             W = W * ((fr * dot(h.n, wi)) / pdf);
-            RT_BOUNCE(fr, dot(h.n, wi), pdf, true);
+            sum.child(fold_of(FOLD_LOBE, fr, dot(h.n, wi), pdf));
             ray.o = h.p;
             ray.d = wi;
         } else if (EXT && m.kind == RTAMD_TRANSPARENT) {
@@ -2394,7 +2415,13 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
                 PendingRay& q = pending[n_pending++];
                 q.o = h.p; q.d = wt; q.W = W * (ft * fabs(dot(h.n, wt)));
                 q.filter = v3(1, 1, 1); q.has_filter = 0; q.depth = lane_depth + 1;
+#ifdef RT_REF_ORDER
+                q.how = fold_of(FOLD_SCALED, v3(0, 0, 0), ft, fabs(dot(h.n, wt)));
+#endif
                 W = W * (dot(h.n, wi) * fr);
+                sum.child(fold_of(FOLD_GLASS_MIRROR, fr, dot(h.n, wi), 0.0));
+            } else {
+                sum.child(fold_of(FOLD_PLAIN, v3(0, 0, 0), 0.0, 0.0));
             }
             ray.o = h.p;
             ray.d = wi;
@@ -2420,7 +2447,13 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
                 q.o = h.p; q.d = wt; q.W = W * (ft * fabs(ndotwt));
                 q.filter = inside ? ld3(m.filter_out) : ld3(m.filter_in);
                 q.has_filter = 1; q.depth = lane_depth + 1;
+#ifdef RT_REF_ORDER
+                q.how = fold_of(FOLD_FRESNEL, q.filter, ft, fabs(ndotwt));
+#endif
                 W = W * ((kr / fabs(ndotwi)) * fabs(ndotwi));
+                sum.child(fold_of(FOLD_FRESNEL, inside ? ld3(m.filter_in) : ld3(m.filter_out), kr / fabs(ndotwi), fabs(ndotwi)));
+            } else {
+                sum.child(fold_of(FOLD_FILTERED, inside ? ld3(m.filter_in) : ld3(m.filter_out), 0.0, 0.0));
             }
             filter = inside ? ld3(m.filter_in) : ld3(m.filter_out);
             has_filter = true;
@@ -2432,7 +2465,6 @@ __device__ __forceinline__ V3 trace_wave(const rtamd_scene_desc& S, const KdStac
     }
     sum.finish(L);
 #undef RT_ADD
-#undef RT_BOUNCE
     return L;
 }
 

@@ -23,13 +23,6 @@ enum { MODE_PIXELS = 0, MODE_RAYS = 1, MODE_TILES = 2 };
 #ifndef RT_BLOCK
 #define RT_BLOCK 64
 #endif
-#ifndef RT_XCD_SEGMENTS
-// XCD-aware work order (multiple of 8 segments; 0 = off).  Measured on the 1080p dragon
-// frame: off 30.8 ms, 8 segments 42.0 (XCDs unevenly loaded), 16 -> 31.6, 32 -> 31.8,
-// 64 -> 31.2.  The 24 MB scene is served from every L2 at 89 % hit rate either way and the
-// kernel is not bound by L2 misses, so the default is off.
-#define RT_XCD_SEGMENTS 0
-#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
@@ -68,7 +61,6 @@ struct LaunchArgs {
     int32_t sample_begin, n_samples, tiles_x;
     int32_t group_shift;        // tile mode: log2 of the samples of one pixel that share a wave (0, 2, 4 or 6)
     int32_t refill;             // refill_kernel: 64-sample groups of the work list one wave owns
-    int64_t seg_len;            // tile mode: waves per XCD segment, 0 = no remap
     rtamd_sample_out out;
     int64_t* sum_rgb8;
     double* sum_sq;
@@ -190,20 +182,14 @@ template <int MODE, int COUNT, int KIND>
 __global__ __launch_bounds__(BLOCK, Kind<KIND>::trees ? RT_MIN_WAVES : RT_MIN_WAVES_ANALYTIC) void trace_kernel(const rtamd_scene_desc S, const LaunchArgs A) {
     typedef Kind<KIND> K;
     constexpr bool TREES = K::trees;
-    // Which 64 samples this wave takes.  Workgroups are dealt to the 8 XCDs round-robin
-    // (blockIdx % 8 shares an L2; observed behaviour, used for speed only).  In tile mode the
-    // work list is cut into RT_XCD_SEGMENTS contiguous segments and segment j is given to
-    // the workgroups of XCD j % 8, so each L2 serves a few bands of the frame instead of
-    // every tile; A.seg_len == 0 keeps the identity order.
+    // Which 64 samples this wave takes: workgroup i takes samples 64 i .. 64 i + 63 of the work list.  (Giving each of
+    // the 8 XCDs, which workgroups are dealt to round-robin, a few contiguous bands of the frame instead measured no
+    // faster in either round - 8 / 16 / 32 / 64 segments - the scene is served from every L2 at more than 80 % hit
+    // rate either way; that remap is no longer in the code.)
 #ifdef RT_PHASE_TIMERS
     const long long wave_start = clock64();
 #endif
-    int64_t wave = blockIdx.x;
-    if (MODE == MODE_TILES && A.seg_len > 0) {
-        const int64_t x = wave & 7, i = wave >> 3;
-        wave = ((i / A.seg_len) * 8 + x) * A.seg_len + (i % A.seg_len);
-    }
-    const int64_t k = wave * BLOCK + threadIdx.x;
+    const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     bool live = k < A.n;
     Work<COUNT> work;
 #ifdef RT_PHASE_TIMERS
@@ -272,11 +258,7 @@ __global__ __launch_bounds__(BLOCK, Kind<KIND>::trees ? RT_MIN_WAVES : RT_MIN_WA
             // pixel are live or dead together (liveness depends on the pixel alone).
             const int32_t stride = 64 >> A.group_shift;
             const bool adds = live && (int32_t)threadIdx.x < stride;
-#ifdef RT_NO_ACCUMULATE
-            if (A.sum_rgb8 && c.x == 12345.678) {
-#else
             if (A.sum_rgb8) {
-#endif
                 long long r = live ? (long long)quantise(c.x) : 0, g = live ? (long long)quantise(c.y) : 0,
                           b = live ? (long long)quantise(c.z) : 0;
                 for (int32_t off = stride; off < 64; off <<= 1) {
@@ -459,15 +441,7 @@ template <int MODE>
 int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_tree_depth, bool bounces, bool fused_always, LaunchArgs& A, uint32_t flags, void* stream) {
     const bool trees = S.n_trees > 0;
     if (A.n <= 0) return RTAMD_OK;
-    A.seg_len = 0;
-#if RT_XCD_SEGMENTS > 0
-    if (MODE == MODE_TILES) {
-        const int64_t waves = (A.n + BLOCK - 1) / BLOCK;
-        if (waves >= 64 * RT_XCD_SEGMENTS) A.seg_len = (waves + RT_XCD_SEGMENTS - 1) / RT_XCD_SEGMENTS;
-    }
-#endif
-    int64_t blocks = (A.n + BLOCK - 1) / BLOCK;
-    if (A.seg_len > 0) blocks = A.seg_len * (RT_XCD_SEGMENTS > 0 ? RT_XCD_SEGMENTS : 1);   // padded: the remap is a bijection
+    const int64_t blocks = (A.n + BLOCK - 1) / BLOCK;
     if (blocks > 0x7fffffffLL) return fail(RTAMD_EINVAL, "too many samples for one launch%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool count = (flags & RTAMD_COUNT_WORK) != 0;
@@ -481,13 +455,9 @@ int launch(const rtamd_scene_desc& S, bool extended, int tree_objects, int max_t
     const bool tiny_trees = max_tree_depth < RT_TINY_DEPTH;
     const bool one_tree_one_light = tree_objects == 1 && S.n_lights == 1;
     bool area_only = false, no_bounce = false, path = false;
-#ifndef RT_NO_AREA_ONLY
     area_only = sums_only && !extended && trees && S.tracer_kind == RTAMD_TRACER_AREA && one_tree_one_light;
-#endif
-#ifndef RT_NO_STRAIGHT
     no_bounce = sums_only && !extended && trees && !area_only && !bounces && S.tracer_kind == RTAMD_TRACER_SHADE && !count && !executed;
     path = sums_only && !extended && trees && S.tracer_kind == RTAMD_TRACER_PATH && !count && !executed;
-#endif
 #if !defined(RT_NO_REFILL) && !defined(RT_ONLY_HOT)
     // waves that refill their lanes: whole frames of scenes without a kd-tree
     if (sums_only && !extended && !count && !executed && !trees) {

@@ -17,11 +17,10 @@ b = json.load(open(sys.argv[1]))
 print("value %.1f %s, ms/step %.3f, kernel %.3f ms" % (b["value"], b["unit"], b["ms_per_step"], b["roofline"]["kernel_ms"]))
 print({k: round(v["frac"], 3) for k, v in b["roofline"]["ceilings"].items()}, b["roofline"]["executed"]["per_ray"])
 PY
-echo "== the worlds of the sweeps whose samples differed: product library, then the checking build (reference order of the bounce sum, LU triangle solve)"
+echo "== the worlds of the sweeps whose samples differed: product library, then the checking build that sums a path in the reference's order (-DRT_REF_ORDER -DRT_NO_REFILL)"
 WORLDS=fuzz_232,fuzz_294,fuzz_1134,fuzzmesh_42,fuzzmesh_762,fuzz_2511,fuzzmesh_1160,fuzz_1337,fuzzmesh_47
 timeout -k 10 300 python tests/fuzz_sweep.py --worlds $WORLDS > "$OUT/knife_edge_worlds_product.log" 2>&1; grep -a "FAILED\|worlds," "$OUT/knife_edge_worlds_product.log"
 RTAMD_LIB=$R/raytracer_amd/csrc/librtamd_reforder_cramer.so timeout -k 10 300 python tests/fuzz_sweep.py --worlds $WORLDS > "$OUT/knife_edge_worlds_reference_order.log" 2>&1; grep -a "FAILED\|worlds," "$OUT/knife_edge_worlds_reference_order.log"
-RTAMD_LIB=$R/raytracer_amd/csrc/librtamd_reforder.so timeout -k 10 300 python tests/fuzz_sweep.py --worlds $WORLDS > "$OUT/knife_edge_worlds_reference_order_and_lu.log" 2>&1; grep -a "FAILED\|worlds," "$OUT/knife_edge_worlds_reference_order_and_lu.log"
 echo "== configurations"
 timeout -k 10 600 python tools/config_rates.py --out "$OUT/rates.json" > "$OUT/rates.log" 2>&1 || { tail -5 "$OUT/rates.log"; exit 1; }
 python - "$OUT/rates.json" <<'PY'

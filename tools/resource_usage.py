@@ -36,7 +36,8 @@ def main():
     keys = (("VGPRs", "vgpr"), ("AGPRs", "agpr"), ("SGPRs", "sgpr"), ("VGPRs Spill", "vgpr_spill"),
             ("SGPRs Spill", "sgpr_spill"), (r"ScratchSize \[bytes/lane\]", "scratch_B_per_lane"),
             (r"Occupancy \[waves/SIMD\]", "waves_per_simd"), (r"LDS Size \[bytes/block\]", "lds_B"))
-    print("trace_kernel<MODE (0 pixels, 1 rays, 2 tiles), COUNT (0 timed, 1 reference work, 2 executed work), EXT, TREES, AREA_ONLY>")
+    print("trace_kernel<MODE (0 pixels, 1 rays, 2 tiles), COUNT (0 timed, 1 reference work, 2 executed work), KIND (0 K_ANALYTIC, 1 K_TREES, "
+          "2 K_EXT, 3 K_AREA_TINY, 4 K_AREA, 5 K_AREA_FUSED, 6 K_STRAIGHT, 7 K_STRAIGHT_ONE, 8 K_PATH)>")
     print("%-44s %s" % ("kernel", " ".join("%18s" % k for _, k in keys)))
     for block in re.split(r"remark: [^\n]*Function Name: ", text)[1:]:
         name = demangle(block.split(" [-Rpass")[0].strip())
