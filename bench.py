@@ -334,7 +334,8 @@ def main():
             parts = host_parts[(args.steps - 1) % 2]        # the last frame as it was delivered to the host
         frame = job.finish(parts)
         line = {
-            "metric": "Mrays/s (whole node) on dragon.obj kd-tree scene",
+            "metric": "Mrays/s (whole node) on dragon.obj kd-tree scene" if scene == "dragon_area" else
+                      "Mrays/s (whole node) on " + args.workload,
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world_size,

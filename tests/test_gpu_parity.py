@@ -646,12 +646,13 @@ def test_refilled_waves_render_the_same_frame(torch_gpu, scene, sample_dim):
     assert torch.equal(part.sum_rgb8.reshape(len(some), 64, 3), want)
 
 
-@pytest.mark.parametrize("scene", ("j", "k", "features_mesh", "mirror"))
+@pytest.mark.parametrize("scene", ("j", "k", "features_mesh", "mirror", "cornellbox", "fuzzmesh_1"))
 def test_accumulator_only_frames_of_kd_scenes(torch_gpu, scene):
     """Whole frames of kd scenes with accumulators only go to kernel builds of their own where the
-    scene allows (materials that spawn no child ray under the plain tracer: `j`, `k`; `mirror` has a
-    mirror floor and stays with the general kernel): they must render what the general kernel
-    reports sample by sample."""
+    scene allows (materials that spawn no child ray under the plain tracer: `j`, `k` - one tree and
+    one light - and `features_mesh`; the path tracer: `cornellbox` as shipped; `mirror` has a mirror
+    floor and stays with the general kernel): they must render what the general kernel reports
+    sample by sample."""
     from raytracer_amd import flatten, runtime
     torch = torch_gpu
     world = common.world_for(scene)
