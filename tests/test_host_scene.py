@@ -189,8 +189,8 @@ def check_shadow_subtrees(dev, nodes, n_nodes, geom, n_rows, whole_trees):
     """Shadow trees: behind `shadow_root` of a tree a kd-tree over all its shadow-casting
     triangles, or (when there is none) behind the seventh float of the box row of every leaf of
     more than 64 rows a kd-tree over that leaf's triangles.  A leaf of such a tree holds every
-    triangle whose (padded) box reaches into the leaf's cell, as copies in appended rows, all
-    inside the leaf's box."""
+    triangle that reaches into the leaf's cell (and none whose padded box does not), as copies in
+    appended rows; what of them lies in the cell is inside the leaf's box."""
     import ctypes as C
     from raytracer_amd import capi, device_layout
     table = dev["leaf_aabb"].reshape(len(nodes), 8)
@@ -227,6 +227,11 @@ def check_shadow_subtrees(dev, nodes, n_nodes, geom, n_rows, whole_trees):
         wide = slack * max(numpy.abs(lo).max(), numpy.abs(hi).max())
         assert slack == 0.0 or wide > 1e-6 * numpy.abs(v).max()
         lo, hi = lo - wide, hi + wide
+        # points of every triangle (a barycentric grid): a triangle with one of them in a leaf's cell must be there
+        grid = [(i / 6.0, j / 6.0) for i in range(7) for j in range(7 - i)]
+        pts = numpy.stack([a * v[0] + b * v[1] + (1.0 - a - b) * v[2] for a, b in grid])       # [point][xyz][triangle]
+        ids = prim[src]
+        assert len(set(ids)) == len(ids)
         todo = [(root, lo.min(axis=0), hi.max(axis=0), 0, numpy.arange(len(src)))]
         seen = numpy.zeros(len(src), dtype=bool)
         while todo:
@@ -235,15 +240,28 @@ def check_shadow_subtrees(dev, nodes, n_nodes, geom, n_rows, whole_trees):
             if (nodes["b"][at] & 3) == 3:
                 f, c = int(nodes["a"][at]), int(nodes["b"][at]) >> 2
                 assert f >= n_rows and c <= device_layout.AUX_MAX_LEAF and nodes["split"][at] < 0
-                # the rows of the leaf are copies of exactly the triangles that reach into its cell
-                assert c == len(members)
-                key = lambda m: sorted(map(bytes, numpy.ascontiguousarray(m.T)))
-                assert key(geom[:, f:f + c]) == key(g[:, members])
-                assert sorted(prim[f:f + c]) == sorted(prim[src[members]])
-                seen[members] = True
+                # the rows of the leaf are copies of triangles whose boxes reach into its cell: of all of them when
+                # boxes were split, else (triangles cut at the planes) of at least those that come within half the
+                # slack of the cell themselves
+                listed = members[numpy.isin(ids[members], prim[f:f + c])]
+                assert len(listed) == c == len(set(prim[f:f + c]))
+                order = numpy.argsort(prim[f:f + c])
+                assert numpy.array_equal(geom[:, f:f + c][:, order], g[:, listed[numpy.argsort(ids[listed])]])
+                seen[listed] = True
+                p = pts[:, :, members]
+                near = ((p >= (cell_lo - 0.5 * wide)[None, :, None]) & (p <= (cell_hi + 0.5 * wide)[None, :, None])).all(axis=1)
+                assert numpy.isin(members[near.any(axis=0)], listed).all()
+                if not device_layout.PERFECT_SPLITS:
+                    assert c == len(members)
                 if c:
+                    # and the leaf's box holds what of them lies in the cell
                     box = table[at, :6].astype(numpy.float64)
-                    assert (lo[members].min(axis=0) >= box[0:3]).all() and (hi[members].max(axis=0) <= box[3:6]).all()
+                    p = pts[:, :, listed]
+                    inside = ((p >= cell_lo[None, :, None]) & (p <= cell_hi[None, :, None])).all(axis=1)
+                    for k in range(3):
+                        assert (p[:, k, :][inside] >= box[k]).all() and (p[:, k, :][inside] <= box[3 + k]).all()
+                    assert (box[0:3] >= lo[listed].min(axis=0) - 1e-6 * (1 + numpy.abs(box[0:3]))).all()
+                    assert (box[3:6] <= hi[listed].max(axis=0) + 1e-6 * (1 + numpy.abs(box[3:6]))).all()
                 continue
             axis, plane, right = int(nodes["b"][at]), float(nodes["split"][at]), int(nodes["a"][at])
             assert 0 <= axis < 3 and cell_lo[axis] < plane < cell_hi[axis] and right > at + 1
