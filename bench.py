@@ -161,7 +161,8 @@ def main():
     if world_size != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world_size, args.gpus))
-    # RTAMD_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks
+    # RTAMD_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks (which is also
+    # what happens by itself there, see below)
     backend = os.environ.get("RTAMD_BENCH_BACKEND", "nccl")
     if os.environ.get("RTAMD_BENCH_LAUNCH_ONLY"):
         # launcher rehearsal without a GPU: rendezvous, one collective, rank 0 reports
@@ -176,14 +177,34 @@ def main():
             json_out.write(json.dumps({"launch_only": True, "n_gpus": world_size, "rank_sum": int(seen[0])}) + "\n")
             json_out.flush()
         return
-    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    # RCCL needs a GPU per rank; with fewer (a rehearsal on a smaller box) the ranks share the GPUs and gather
+    # over gloo, and so they do when RCCL does not come up - the line says which (config.backend)
+    n_dev = max(torch.cuda.device_count(), 1)
+    backend_note = None
+    if backend == "nccl" and world_size > n_dev and not os.environ.get("RTAMD_BENCH_FORCE_RCCL"):
+        backend, backend_note = "gloo", "%d ranks on %d GPU(s): gloo instead of RCCL" % (world_size, n_dev)
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world_size,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                        device_id=torch.device("cuda", local_rank))
+                ones = torch.ones(1, dtype=torch.int64, device="cuda")
+                dist.all_reduce(ones)                   # the communicator is built here at the latest
+                torch.cuda.synchronize()
+                if int(ones[0]) != world_size:
+                    raise RuntimeError("RCCL all_reduce of ones over %d ranks gave %d" % (world_size, int(ones[0])))
+            except Exception as exc:                    # every rank fails alike (driver, IPC or topology trouble)
+                backend_note = "RCCL did not come up (%s): gloo instead" % (str(exc).strip().splitlines() or ["?"])[0][:160]
+                log("rank %d: %s" % (rank, backend_note))
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                backend = "gloo"
+        if backend != "nccl":
             dist.init_process_group(backend, rank=rank, world_size=world_size)
 
     from raytracer_amd.world import World
@@ -350,7 +371,9 @@ def main():
             "config": {"workload": args.workload, "scene": scene, "resolution": list(world.viewplane.resolution),
                        "samples_per_pixel": n_samples, "rays_per_frame": rays_per_frame,
                        "samples_per_frame": total_samples / float(args.steps),
-                       "tiles": "8x8 px, diagonal interleave over ranks, RCCL gather to rank 0",
+                       "tiles": "8x8 px, diagonal interleave over ranks, gather to rank 0",
+                       "backend": ("RCCL" if backend == "nccl" else backend) if world_size > 1 else None,
+                       "backend_note": backend_note,
                        "scene_bytes": ds.flat.nbytes(), "host_scene_build_s": round(t_build, 2),
                        "frame_mean_rgb": [float(x) for x in frame.reshape(-1, 3).mean(axis=0)]},
             "roofline": {"bound": "hbm",

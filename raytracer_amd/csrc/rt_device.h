@@ -1936,6 +1936,7 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
             r1.o = h.p;
             r1.d = v3(0, 0, 1);
             if (lit) r1.d = hemisphere_about(h.n, draw_hemisphere(S, S.ambient.sampler, dr));
+            w.mark(60);     // material record, occlusion ray
             // the light's direction, term and shadow ray, as in the loop below
             V3 wi = v3(0, 0, 1), sample_point = v3(0, 0, 0);
             if (lit) {
@@ -1952,6 +1953,7 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
                 default: wi = hemisphere_about(h.n, draw_hemisphere(S, lt.sampler, dr)); break;
                 }
             }
+            w.mark(61);     // light sample and direction
             const double ndotwi = dot(h.n, wi);
             const bool facing = lit && ndotwi > 0;
             const bool phong = m.kind != RTAMD_MATTE;
@@ -1978,6 +1980,7 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
                     term = (term * G) / pdf;
                 }
             }
+            w.mark(62);     // the light's term
             Ray r2;
             r2.o = h.p;
             r2.d = wi;
@@ -2000,6 +2003,7 @@ __device__ __forceinline__ V3 direct_light_wave(const rtamd_scene_desc& S, const
             // (fused_always: the emitter lies outside the tree's box by a margin along some axis, so a light
             // ray that is inside the box before its limit has left it again by then, whatever rounding does
             // to the two distances)
+            w.mark(63);     // both rays in the tree's space, their way through its box
             if (stk.fused_always || !__ballot(in2 && !free2)) {
                 w.mark(34);
                 // light.in_shadow for both rays: the analytic objects first, the tree last

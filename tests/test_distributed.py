@@ -237,3 +237,27 @@ def test_two_ranks_over_rccl_equal_one_rank(tmp_path):
     World.__init__(world, viewmode="parallel", buildfunction="cornellbox_area", seed=3)
     single, _ = runtime.render_image(world, mode="parallel")
     assert numpy.array_equal(numpy.load(out), single)
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_gathers_over_gloo_when_rccl_is_refused():
+    """`bench.py --gpus 2` on a box with one GPU: RCCL refuses two ranks on one device, the ranks say so and
+    gather over gloo instead; with two GPUs the same command runs over RCCL."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "RTAMD_BENCH_BACKEND")}
+    env["RTAMD_BENCH_FORCE_RCCL"] = "1"         # do not skip RCCL because of the device count: let it refuse
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "cornellbox_200_16spp_arealight", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and len(line["ranks"]["kernel_ms"]) == 2
+    assert line["roofline"]["executed"]["same_frame_as_timed_kernel"]
+    if torch.cuda.device_count() < 2:
+        assert line["config"]["backend"] == "gloo" and "RCCL did not come up" in line["config"]["backend_note"]
+    else:
+        assert line["config"]["backend"] == "RCCL" and line["config"]["backend_note"] is None

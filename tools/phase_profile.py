@@ -90,8 +90,12 @@ def main():
         out["packed_shadow_sharing"] = {"episodes": t[27], "rays": t[25], "distinct_leaves": t[26]}
     out["marks_inclusive"] = {"closest_hit_incl_kd": (t[31] + t[44] + t[45] + t[46]) / float(total), "ambient_occlusion_incl_kd": t[18] / float(total),
                               "light_shadow_incl_kd": t[19] / float(total), "ray_generation": t[32] / float(total),
-                              "hit_to_ambient_ray": t[33] / float(total), "light_setup": t[34] / float(total),
+                              "hit_to_ambient_ray": t[33] / float(total), "light_setup": (t[34] + sum(t[60:64])) / float(total),
                               "shade_and_write": t[35] / float(total)}
+    if sum(t[60:64]):
+        out["light_setup_parts"] = {"material_record_and_occlusion_ray": t[60] / float(total), "light_sample_and_direction": t[61] / float(total),
+                                    "light_term": t[62] / float(total), "rays_in_tree_space_and_root_boxes": t[63] / float(total),
+                                    "rest": t[34] / float(total)}
     out["closest_hit_parts"] = {"before_kd_query": t[44] / float(total), "kd_query_with_root_box": t[45] / float(total),
                                 "hit_row_normal_and_material": t[46] / float(total),
                                 "analytic_objects_and_the_rest": t[31] / float(total)}
