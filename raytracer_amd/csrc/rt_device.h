@@ -796,7 +796,9 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
                 int32_t near_n, far_n;
                 if (split >= o) { near_n = node + 1; far_n = nd.a; }
                 else            { near_n = nd.a;     far_n = node + 1; }
-                if (t >= t_far || t < 0) {
+                // (the sign bit, not t < 0: an origin that lies on the plane in single precision gives t = -0 for a
+                // ray that leaves it towards the near side and +0 for one that leaves it towards the far side)
+                if (t >= t_far || __float_as_int(t) < 0) {
                     node = near_n;
                 } else if (t <= t_near) {
                     node = far_n;
@@ -829,7 +831,7 @@ __device__ __forceinline__ void shadow_tree_wave(const rtamd_scene_desc& S, cons
 #ifdef RT_PHASE_TIMERS
                 if (fresh) {
                     atomicAdd(&g_phase_cycles[fresh == 1 ? 55 : 59], (unsigned long long)levels);
-                    atomicAdd(&g_phase_cycles[fresh == 1 ? 56 : 60], (unsigned long long)sp);     // entries pushed on the way
+                    if (fresh == 1) atomicAdd(&g_phase_cycles[56], (unsigned long long)sp);       // entries pushed on the way
                     fresh = 0;
                 }
 #endif
@@ -1005,29 +1007,23 @@ __device__ __forceinline__ void kd_query_wave(const rtamd_scene_desc& S, const r
     // only rays with a limit inside the tree's box go on below, on the reference's tree
     if (STEAL && S.leaf_aabb != nullptr && T.shadow_root > 0) {
         const bool fast = steal_ok;
-        if (__ballot(fast)) {
-            bool f2 = false;
-            TriHit b2;
-            b2.t = 0;
-            shadow_tree_wave<COUNT>(S, T, fast, r, t_near, t_exit, limit_in > T_INF, stk, w, f2, b2);
-            if (fast) { out_found = f2; out_t = b2.t; walking = false; }
-        }
-        if (!__ballot(walking)) { found = out_found; best.t = out_t; return; }
         // A ray that ends inside the tree's box (a light among the triangles: the reference's j.py)
         // is answered by the first item in scan order that it hits, wherever on the ray that hit
         // lies - the reference's walk, below.  But when no triangle at all is hit before the limit,
         // that walk finds either nothing or a hit beyond the limit, and the ray is not occluded
         // either way: the shadow tree, walked up to the limit, proves that faster, and only rays
-        // with some hit in there go on to the exact walk.
+        // with some hit in there go on to the exact walk.  Both kinds walk the shadow tree in one query.
         const bool limited = stk.prefilter_ok && walking && !fast;
-        if (__ballot(limited)) {
-            bool f3 = false;
-            TriHit b3;
-            b3.t = 0;
-            shadow_tree_wave<COUNT>(S, T, limited, r, t_near, fmin(t_exit, limit * (1.0 + 1e-6) + 1e-6), false, stk, w, f3, b3);
-            if (limited && !f3) walking = false;
-            if (!__ballot(walking)) { found = out_found; best.t = out_t; return; }
+        if (__ballot(fast || limited)) {
+            bool f2 = false;
+            TriHit b2;
+            b2.t = 0;
+            const double far = fast ? t_exit : fmin(t_exit, limit * (1.0 + 1e-6) + 1e-6);
+            shadow_tree_wave<COUNT>(S, T, fast || limited, r, t_near, far, limit_in > T_INF, stk, w, f2, b2);
+            if (fast) { out_found = f2; out_t = b2.t; walking = false; }
+            if (limited && !f2) walking = false;
         }
+        if (!__ballot(walking)) { found = out_found; best.t = out_t; return; }
         steal_ok = false;
     }
     PhaseClock clk;

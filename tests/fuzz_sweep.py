@@ -30,8 +30,10 @@ def main():
         if len(a) > 2:
             jobs += [("fuzzmesh_%d", fuzz._make_mesh, k) for k in range(a[2], a[3])]
     bad = 0
-    for pattern, make, k in jobs:
+    for done, (pattern, make, k) in enumerate(jobs):
         name = pattern % k
+        if done % 50 == 0:
+            print("... %d of %d worlds, %d failed so far" % (done, len(jobs), bad), flush=True)
         if k >= (fuzz.N_WORLDS if make is fuzz._make else fuzz.N_MESH_WORLDS):
             make(k)
         try:

@@ -77,6 +77,22 @@ def test_random_teapot_worlds_match_oracle(torch_gpu, first):
         check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), 96, None, "fuzzmesh_%d" % k)
 
 
+def test_shadow_walk_from_an_origin_on_a_split_plane(torch_gpu):
+    """`fuzzmesh_2031`, a world of the hand-run sweep: an ambient-occlusion ray starts on the ground at an x that,
+    rounded to single precision, equals a split plane of the teapot's shadow tree, and leaves the plane towards
+    the side the walk calls near.  The plane's distance is then -0: a walk that asks `t < 0` takes it for a
+    crossing at the start of the ray, goes to the far side alone and misses the triangle the ray hits (one
+    sample of the frame came out unoccluded); the walk asks for the sign bit."""
+    import sys
+    from raytracer_amd import flatten
+    from raytracer_amd.world import World
+    World(viewmode="parallel", buildfunction="fuzz_0", seed=1)       # loads the scene files
+    fuzz = [m for name, m in sys.modules.items() if name.startswith("rtamd_scene_fuzz")][0]
+    fuzz._make_mesh(2031)
+    world = World(viewmode="parallel", buildfunction="fuzzmesh_2031", seed=1)
+    check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), 96, None, "fuzzmesh_2031")
+
+
 def check_tiles_against_oracle(torch, world, flat, tiles, samples, scene):
     from raytracer_amd import flatten, runtime
     from oracle import oracle
