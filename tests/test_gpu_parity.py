@@ -93,6 +93,66 @@ def test_shadow_walk_from_an_origin_on_a_split_plane(torch_gpu):
     check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), 96, None, "fuzzmesh_2031")
 
 
+def test_shadow_rays_that_start_on_the_planes_of_the_shadow_tree(torch_gpu):
+    """Shadow rays whose origin has, in single precision, exactly the coordinate of a split plane of the mesh's
+    shadow tree, for every plane of the tree: primary rays straight down onto the ground (x or z of a plane) and
+    straight at the back wall (x or y of a plane), beside the teapot, so that the occlusion rays and the light's
+    rays of those hits start on a plane and outside the tree's box.  The kernels that walk the shadow tree in
+    single precision must answer like the kernel that follows the reference's walk."""
+    import ctypes as C
+    import raytracer_amd
+    raytracer_amd.activate()
+    from light import AmbientOccluder
+    from raytracer_amd import capi, device_layout, flatten, runtime
+    from raytracer_amd.world import World
+    from geometry import Plane
+    from material import Matte
+    world = World(viewmode="parallel", buildfunction="k", seed=3)
+    world.ambient_color = AmbientOccluder(numpy.array((1., 1., 1.)), .4, world.viewplane.sampler)
+    world.objects.append(Plane(origin=(0, 0, 8), normal=(0, 0, -1), material=Matte(ka=1, kd=1, cd=numpy.array((1., .84, 1.)))))
+    world.invalidate()
+    flat = flatten.flatten_world(world)
+    dev, _ = device_layout.device_arrays(flat)
+    raw = bytes(dev["trees"])
+    tree = (capi.Tree * (len(raw) // C.sizeof(capi.Tree))).from_buffer_copy(raw)[0]
+    assert tree.shadow_root > 0
+    nodes = numpy.frombuffer(dev["kd_nodes"], dtype=numpy.dtype([("split", "<f8"), ("a", "<i4"), ("b", "<i4")]))[tree.shadow_root:]
+    lo, hi = numpy.array(tree.bbox_lo), numpy.array(tree.bbox_hi)
+    origins, directions = [], []
+    for axis in range(3):
+        planes = numpy.unique(nodes["split"][nodes["b"] == axis].astype(numpy.float32)).astype(numpy.float64)
+        assert len(planes) > 100
+        for k, c in enumerate(planes):
+            if axis != 1:
+                # onto the ground (y = 0) in front of, or behind, or beside the box
+                other = (hi[2 - axis] + 0.4 + 0.13 * (k % 7)) if k % 2 else (lo[2 - axis] - 0.4 - 0.13 * (k % 5))
+                at = [0., 3., 0.]
+                at[axis], at[2 - axis] = c, other
+                origins.append(at)
+                directions.append((0., -1., 0.))
+            if axis != 2:
+                # at the back wall (z = 8): x or y of a plane
+                at = [hi[0] + 0.3 + 0.11 * (k % 5), 0.2 + 0.09 * (k % 11), 5.]
+                at[axis] = c
+                origins.append(at)
+                directions.append((0., 0., 1.))
+    origins, directions = numpy.array(origins), numpy.array(directions)
+    n = len(origins)
+    ds = runtime.device_scene(world)
+    checked = 0
+    for sample in range(4):
+        pix = (numpy.arange(n) * 7 + sample) .astype(numpy.int32) % (world.viewplane.resolution[0] * world.viewplane.resolution[1])
+        smp = numpy.full(n, sample, dtype=numpy.int32)
+        fast = ds.trace_rays(world.seed, origins, directions, pix, smp)
+        exact = ds.trace_rays(world.seed, origins, directions, pix, smp, count_work=True)
+        assert numpy.array_equal(fast["hit_object"], exact["hit_object"]) and numpy.array_equal(fast["n_rays"], exact["n_rays"])
+        differ = numpy.nonzero(~numpy.isclose(fast["rgb"], exact["rgb"], rtol=1e-12, atol=0, equal_nan=True).all(axis=1))[0]
+        assert len(differ) == 0, "sample %d: %d of %d rays differ, first: origin %s fast %s exact %s" % (
+            sample, len(differ), n, origins[differ[0]], fast["rgb"][differ[0]], exact["rgb"][differ[0]])
+        checked += int((fast["n_rays"][:, 1] > 0).sum())
+    assert checked > 2 * n          # the hits cast shadow rays
+
+
 def check_tiles_against_oracle(torch, world, flat, tiles, samples, scene):
     from raytracer_amd import flatten, runtime
     from oracle import oracle
