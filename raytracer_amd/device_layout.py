@@ -61,7 +61,9 @@ def _morton_order(centroids):
 
 
 SHADOW_TREE_SLACK = 4.0e-5        # see shadow_tree_wave in csrc/rt_device.h
-SHADOW_TREE_MIN_ROWS = 512      # trees with at least this many rows get a shadow tree of their own
+# trees with at least this many rows get a shadow tree of their own (RTAMD_SHADOW_TREE_MIN_ROWS: test runs that
+# send the shadow rays of big meshes down the paths of small ones - the reference's tree, shadow subtrees of leaves)
+SHADOW_TREE_MIN_ROWS = int(os.environ.get("RTAMD_SHADOW_TREE_MIN_ROWS", "512"))
 AUX_MIN_ROWS = CHUNK  # leaves of more rows than this get a shadow subtree
 AUX_LEAF = 16       # rows at which a shadow subtree stops splitting
 AUX_MAX_LEAF = 64   # a shadow subtree whose build leaves more rows than this in a leaf is dropped

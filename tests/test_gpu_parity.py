@@ -861,3 +861,32 @@ def test_shadow_tree_paths_of_the_whole_frame_kernel(torch_gpu, case):
     world, tiles, samples = shadow_path_world(case)
     world.invalidate()
     check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), tiles, samples, case)
+
+
+def test_pack_sums_saturates_and_clears(torch_gpu):
+    """rtamd_pack_sums: a rank's 64-bit sums become the int32 values that travel to rank 0 (saturated: a sum only
+    leaves the int32 range where samples were infinite, and such a pixel is clamped on arrival anyway,
+    main.py:104-106); with `clear` the sums are zeroed in the same pass.  Odd sizes, nothing to do, bad arguments."""
+    import ctypes as C
+    from raytracer_amd import capi, runtime
+    torch = torch_gpu
+    ds = runtime.device_scene(common.world_for("foursphere"))
+    big = 2 ** 31
+    for n in (1, 255, 256, 257, 3 * 64 * 1000 + 5):
+        g = torch.Generator().manual_seed(n)
+        sums = torch.randint(-1000, 70000, (n,), generator=g, dtype=torch.int64)
+        sums[::7] = torch.tensor([big - 1, big, big + 12345, -big, -big - 1, 2 ** 62, -2 ** 62])[torch.arange(len(sums[::7])) % 7]
+        want = sums.clamp(-big, big - 1).to(torch.int32)
+        for clear in (False, True):
+            dev = sums.clone().cuda()
+            wire = torch.full((n,), 77, dtype=torch.int32, device="cuda")
+            ds.pack_sums(dev, wire, clear=clear)
+            torch.cuda.synchronize()
+            assert torch.equal(wire.cpu(), want)
+            assert torch.equal(dev.cpu(), torch.zeros_like(sums) if clear else sums)
+    lib = capi.library()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.rtamd_pack_sums(None, None, 0, 1, stream) == 0                 # nothing to do
+    assert lib.rtamd_pack_sums(None, None, 5, 1, stream) == -1                # RTAMD_EINVAL
+    assert b"null" in lib.rtamd_last_error()
+    assert lib.rtamd_pack_sums(None, None, -1, 0, stream) == -1
