@@ -502,7 +502,7 @@ const char *rtamd_kd_last_error(void);
  * max_nodes rows).  With the output arrays NULL only the sizes are worked out (n_nodes, n_leaves,
  * n_rows, depth = levels).
  * RTAMD_EUNSUPPORTED: within max_depth levels some leaf would keep more than max_leaf_rows;
- * RTAMD_EINVAL also when the host runs out of memory. */
+ * RTAMD_EINVAL also for coordinates that are not finite numbers, and when the host runs out of memory. */
 int rtamd_shadow_tree_build(const double *box_lo, const double *box_hi, int64_t n_boxes, int32_t max_depth,
                             int32_t leaf_rows, int32_t max_leaf_rows, double step_cost,
                             const double *tri_corners, double slack,

@@ -196,12 +196,17 @@ extern "C" int rtamd_shadow_tree_build(const double* box_lo, const double* box_h
     for (int64_t i = 0; i < n_boxes; ++i) {
         all[(size_t)i].tri = (int32_t)i;
         for (int ax = 0; ax < 3; ++ax) {
+            // (a coordinate that is not a number would break the order the sweeps below sort by)
+            if (!std::isfinite(box_lo[i * 3 + ax]) || !std::isfinite(box_hi[i * 3 + ax])) return RTAMD_EINVAL;
             all[(size_t)i].lo[ax] = box_lo[i * 3 + ax];
             all[(size_t)i].hi[ax] = box_hi[i * 3 + ax];
             cell_lo[ax] = std::min(cell_lo[ax], box_lo[i * 3 + ax]);
             cell_hi[ax] = std::max(cell_hi[ax], box_hi[i * 3 + ax]);
         }
     }
+    if (tri_corners)
+        for (int64_t i = 0; i < n_boxes * 9; ++i)
+            if (!std::isfinite(tri_corners[i])) return RTAMD_EINVAL;
     b.build(all, cell_lo, cell_hi, 0);
     std::vector<Ref>().swap(all);
     if (b.overflow) return RTAMD_EUNSUPPORTED;          // some leaf keeps more than max_leaf_rows rows

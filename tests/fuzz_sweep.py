@@ -35,7 +35,7 @@ def main():
         if done % 50 == 0:
             print("... %d of %d worlds, %d failed so far" % (done, len(jobs), bad), flush=True)
         if k >= (fuzz.N_WORLDS if make is fuzz._make else fuzz.N_MESH_WORLDS):
-            make(k)
+            keep = make(k)      # (held: build functions are found through their base class, which does not hold them)
         try:
             world = World(viewmode="parallel", buildfunction=name, seed=1)
             t.check_tiles_against_oracle(torch, world, flatten.flatten_world(world), 96, None, name)

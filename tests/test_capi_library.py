@@ -98,6 +98,14 @@ def test_shadow_tree_builder_on_the_host():
     assert call(same_lo, same_hi, 30, 8, 64) == capi.EUNSUPPORTED
     assert call(same_lo, same_hi, 30, 8, 128) == 0 and (n_nodes.value, n_leaves.value, n_rows.value) == (1, 1, 100)
     assert call(lo, hi, 30, 0, 64) == -1 and call(lo, hi, -1, 8, 64) == -1 and call(lo, hi, 30, 16, 8) == -1
+    # coordinates that are not numbers are refused (they would break the order the builder sorts by)
+    for bad in (numpy.nan, numpy.inf):
+        broken = hi.copy()
+        broken[123, 1] = bad
+        assert call(lo, broken, 30, 8, 64) == -1
+        corners = numpy.ascontiguousarray(numpy.concatenate([lo, hi, lo], axis=1))
+        corners[77, 4] = bad
+        assert call(lo, hi, 30, 8, 64, corners=corners, slack=1e-6) == -1
 
 
 def test_shadow_tree_builder_splits_triangles_at_the_planes():
