@@ -9,7 +9,9 @@ LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(HERE, "csrc", "librtamd.s
 
 ABI_VERSION = 7
 MAX_BRANCH_LEVELS = 8
-MAX_TREE_DEPTH = 38           # levels a walk may pass through (the kernels' stack holds 40 entries)
+# levels a walk may pass through: the kernels' stack holds RT_STACK_MAX = 40 entries; a library built with a larger
+# -DRT_STACK_MAX takes deeper trees (RTAMD_MAX_TREE_DEPTH = that value - 2 tells the host side)
+MAX_TREE_DEPTH = int(os.environ.get("RTAMD_MAX_TREE_DEPTH", "38"))
 N_COUNTERS = 16
 COUNT_WORK = 1
 COUNT_EXECUTED = 2
