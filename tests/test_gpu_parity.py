@@ -890,3 +890,27 @@ def test_pack_sums_saturates_and_clears(torch_gpu):
     assert lib.rtamd_pack_sums(None, None, 5, 1, stream) == -1                # RTAMD_EINVAL
     assert b"null" in lib.rtamd_last_error()
     assert lib.rtamd_pack_sums(None, None, -1, 0, stream) == -1
+
+
+@pytest.mark.parametrize("scene", ("mirrorhall_dof", "cornellbox_area"))
+def test_one_launch_of_more_than_two_to_the_31_samples(torch_gpu, scene):
+    """A frame of 8192x4320 pixels at 64 samples per pixel is 2.26e9 samples in one launch: sample numbers beyond
+    the 32-bit range (the mirror hall: waves that refill their lanes; the Cornell box: one sample per lane, a
+    kd-tree).  Tiles from the start, the middle and the end of that launch equal the same tiles rendered alone."""
+    from raytracer_amd import flatten, runtime
+    torch = torch_gpu
+    world = _tiny_world(scene, resolution=(8192, 4320), sample_dim=8)
+    ds = runtime.device_scene(world)
+    cam = flatten.camera_record(world)
+    tx, ty = runtime.tile_grid(cam.width, cam.height)
+    n_tiles = tx * ty
+    assert n_tiles * 64 * 64 > 2 ** 31
+    whole = runtime.FrameBuffers(ds, numpy.arange(n_tiles, dtype=numpy.int32))
+    ds.render_tiles(cam, world.seed, whole.tile_ids, 0, 64, sum_rgb8=whole.sum_rgb8)
+    some = numpy.array([0, 1, tx - 1, n_tiles // 2 + 17, n_tiles - tx, n_tiles - 2, n_tiles - 1], dtype=numpy.int32)
+    alone = runtime.FrameBuffers(ds, some)
+    ds.render_tiles(cam, world.seed, alone.tile_ids, 0, 64, sum_rgb8=alone.sum_rgb8)
+    torch.cuda.synchronize()
+    rows = (torch.as_tensor(some, dtype=torch.int64)[:, None] * 64 + torch.arange(64)[None, :]).reshape(-1).to(whole.sum_rgb8.device)
+    assert torch.equal(whole.sum_rgb8[rows], alone.sum_rgb8)
+    assert int((whole.sum_rgb8.sum(dim=1) > 0).sum()) > n_tiles * 32        # the frame is not empty
