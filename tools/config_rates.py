@@ -30,6 +30,8 @@ CONFIGS = [
     # the reference's scene files at a frame size that fills the GPU: (width, height, sampler dimension)
     ("J dragon of j.py at 1920x1080 4spp (Matte, point light)", "j", None, (1920, 1080, 2)),
     ("K teapot of k.py at 1920x1080 4spp", "k", None, (1920, 1080, 2)),
+    ("2 cornellbox_area at 1920x1080 16spp (a frame that fills the GPU)", "cornellbox_area", dict(resolution=(1920, 1080), sample_dim=4)),
+    ("1 foursphere at 1920x1080 16spp (a frame that fills the GPU)", "foursphere", None, (1920, 1080, 4)),
 ]
 
 
