@@ -3,6 +3,8 @@ path in combinations nobody wrote down by hand.  Test scenes of this project, wr
 against the reference's scene API only, so the reference itself renders them when golden
 vectors are generated.  `fuzz_<k>`: k % 3 picks the tracer (Tracer, AreaLightTracer,
 WhittedTracer), everything else follows from numpy.random.RandomState(4000 + k)."""
+import os
+
 import numpy
 import affinetransform as transform
 from buildfunctionbase import BuildFunctionBase
@@ -87,6 +89,8 @@ def build_world(world, viewmode, k):
     kind = k % 3
     world.viewmode = viewmode
     dim = 1 if viewmode == "realtime" else int(r.choice([1, 2, 3]))
+    if viewmode != "realtime" and os.environ.get("RTAMD_FUZZ_DIM"):
+        dim = int(os.environ["RTAMD_FUZZ_DIM"])     # hand-run sweeps at other sample counts (4: waves of 2x2 pixels x 16 samples)
     sampler = RegularSampler() if viewmode == "realtime" else MultiJitteredSampler(sample_dim=dim)
     lobe_e = float(r.choice([5, 25, 100]))
     lobe = MultiJitteredSampler(sample_dim=max(dim, 2), e=lobe_e)
@@ -202,6 +206,8 @@ def build_mesh_world(world, viewmode, k):
     kind = k % 3
     world.viewmode = viewmode
     dim = int(r.choice([1, 2]))
+    if os.environ.get("RTAMD_FUZZ_DIM"):
+        dim = int(os.environ["RTAMD_FUZZ_DIM"])
     sampler = MultiJitteredSampler(sample_dim=dim)
     lobe_e = float(r.choice([5, 25, 100]))
     lobe = MultiJitteredSampler(sample_dim=2, e=lobe_e)

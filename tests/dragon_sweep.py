@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off sweep over random variations of the benchmark's dragon world (the mesh, its kd-tree and its shadow
 tree are those of configuration 4; camera, emitter, materials and ambient light vary):
-  python tests/dragon_sweep.py FIRST LAST
+  python tests/dragon_sweep.py FIRST LAST [SAMPLER_DIMENSION]
 Every world goes through tests/test_gpu_parity.check_tiles_against_oracle on 48 random tiles of a 160x96 frame
 (every sample; ids / ray counts / reference work exact, the timed and both counting kernels the same frame).
 Needs a GPU; about five seconds per world, most of it the host-side tables."""
@@ -70,7 +70,8 @@ def main():
     from raytracer_amd import flatten
     import test_gpu_parity as t
     first, last = int(sys.argv[1]), int(sys.argv[2])
-    world = t._tiny_world("dragon_area", resolution=(160, 96), sample_dim=2, seed=5)
+    dim = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # 2: waves of 4x4 pixels x 4 samples; 4: 2x2 pixels x 16 samples, as in the benchmark
+    world = t._tiny_world("dragon_area", resolution=(160, 96) if dim <= 2 else (96, 56), sample_dim=dim, seed=5)
     bad = 0
     t0 = time.time()
     for k in range(first, last):
@@ -79,7 +80,7 @@ def main():
             print("... %d of %d worlds, %d failed so far, %.0f s" % (k - first, last - first, bad, time.time() - t0), flush=True)
         try:
             vary(world, k)
-            t.check_tiles_against_oracle(torch, world, flatten.flatten_world(world), 48, None, name)
+            t.check_tiles_against_oracle(torch, world, flatten.flatten_world(world), 48 if dim <= 2 else 40, None, name)
         except Exception:
             bad += 1
             print("FAILED %s" % name, flush=True)
