@@ -18,7 +18,7 @@ from material import (Dielectric, Emissive, GlossyReflective, Matte, Phong, Refl
                       Transparent)
 from mesh_parser import read_mesh
 from sampler import MultiJitteredSampler, RegularSampler
-from tracer import AreaLightTracer, Tracer, ViewPlane, WhittedTracer
+from tracer import AreaLightTracer, PathTracer, Tracer, ViewPlane, WhittedTracer
 
 N_WORLDS = 128
 
@@ -280,3 +280,85 @@ def _make_mesh(k):
 
 
 MESH_WORLDS = [_make_mesh(k) for k in range(N_MESH_WORLDS)]
+
+
+# ---- `fuzzpath_<k>`: path-traced worlds (Matte and Emissive materials, tracer.py:74-88, material.py:283-289)
+N_PATH_WORLDS = 6
+
+
+def build_path_world(world, viewmode, k):
+    """Random analytic objects, two kinds of mesh (mesh1's 70 triangles in a tree of a few levels, the teapot in a
+    tree with a shadow tree that path tracing never asks) and emitters, all Matte or Emissive, under the
+    PathTracer: every hit draws one direction about the normal and goes on, up to the depth limit."""
+    r = numpy.random.RandomState(52000 + k)
+    world.viewmode = viewmode
+    dim = int(r.choice([1, 2, 3]))
+    if os.environ.get("RTAMD_FUZZ_DIM"):
+        dim = int(os.environ["RTAMD_FUZZ_DIM"])
+    sampler = MultiJitteredSampler(sample_dim=dim)
+    bounce = MultiJitteredSampler(sample_dim=2, e=float(r.choice([1, 1, 5])))
+    world.viewplane = ViewPlane(resolution=(96, 64), pixel_size=3.3, sampler=sampler)
+    angle = float(r.uniform(0, 2 * numpy.pi))
+    eye = (float(round(10 * numpy.cos(angle), 3)), float(round(r.uniform(2, 6), 3)), float(round(10 * numpy.sin(angle), 3)))
+    world.camera = PinholeCamera(eye=eye, up=(0., 1., 0.), lookat=(0., 1.2, 0.), viewing_distance=330.)
+    world.background_color = numpy.array([float(x) for x in numpy.round(r.uniform(0, .2, 3), 2)])
+    world.tracer = PathTracer(world)
+    world.tracer.depth_limit = int(r.randint(1, 6))
+    world.ambient_color = AmbientLight(numpy.array((1., 1., 1.)), .2)
+    world.lights = []
+
+    def matte():
+        return Matte(ka=.5, kd=float(round(r.uniform(.4, .95), 2)), cd=_colour(r), sampler=bounce)
+
+    def glow():
+        return Emissive(float(round(r.uniform(2, 12), 1)), _colour(r))
+    objects = [Plane(origin=(0, 0, 0), normal=(0, 1, 0), material=matte())]
+    if r.rand() < 0.5:
+        objects.append(Plane(origin=(0, 0, -7), normal=(0, 0, 1), material=matte()))
+    if r.rand() < 0.6:
+        with open('meshes/teapot.obj') as f:
+            mesh = read_mesh(f)
+        if r.rand() < 0.5:
+            mesh.compute_smooth_normal()
+        mesh.material = matte()
+        pot = KDTree(BoundingBoxes(mesh.get_bounding_boxes()))
+        objects.append(pot if r.rand() < 0.5 else Instance(pot, _transform(r, (0., 0., 0.))))
+    for _ in range(int(r.randint(3, 8))):
+        where = _vec(r, -4, 4) * numpy.array((1., 0., 1.)) + numpy.array((0., float(r.uniform(.4, 2.5)), 0.))
+        mat = glow() if r.rand() < 0.3 else matte()
+        shape = int(r.randint(0, 6))
+        if shape == 0:
+            obj = Sphere(center=where, radius=float(round(r.uniform(.4, 1.3), 2)), material=mat)
+        elif shape == 1:
+            half = _vec(r, .3, 1.0)
+            lo, hi = where - half, where + half
+            obj = AxisAlignedBox(float(lo[0]), float(hi[0]), float(lo[1]), float(hi[1]), float(lo[2]), float(hi[2]), material=mat)
+        elif shape == 2:
+            obj = Rectangle(where + numpy.array((0., 2., 0.)), float(round(r.uniform(1, 3), 1)), float(round(r.uniform(1, 3), 1)),
+                            numpy.array((0., -1., 0.)), numpy.array((1., 0., 0.)), mat, sampler)
+        elif shape == 3:
+            obj = Instance(Sphere(center=numpy.zeros(3), radius=1., material=mat), _transform(r, where))
+        elif shape == 4:
+            obj = Instance(_mesh_tree('meshes/mesh1.obj', mat, bool(r.rand() < 0.5)),
+                           _transform(r, where).dot(transform.scale(7., 7., 7.)))
+        else:
+            obj = _soup(r, int(r.randint(30, 120)), mat)
+        objects.append(obj)
+    # something to see by
+    objects.append(Sphere(center=numpy.array((float(r.uniform(-3, 3)), float(r.uniform(5, 8)), float(r.uniform(-3, 3)))),
+                          radius=float(round(r.uniform(.8, 2.0), 2)), material=glow()))
+    world.objects = objects
+
+
+def _make_path(k):
+    class FuzzPath(BuildFunctionBase):
+        BUILD_FUNCTION_NAME = 'fuzzpath_%d' % k
+
+        @classmethod
+        def build_function(cls, world, viewmode):
+            build_path_world(world, viewmode, k)
+    FuzzPath.__name__ = 'FuzzPath%d' % k
+    return FuzzPath
+
+
+PATH_WORLDS = [_make_path(k) for k in range(N_PATH_WORLDS)]

@@ -77,6 +77,17 @@ def test_random_teapot_worlds_match_oracle(torch_gpu, first):
         check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), 96, None, "fuzzmesh_%d" % k)
 
 
+def test_random_path_traced_worlds_match_oracle(torch_gpu):
+    """Six seeded path-traced worlds (`fuzzpath_<k>`, raytracer_amd/scenes/fuzz.py): Matte and Emissive analytic
+    objects, mesh1 in a tree of a few levels, the teapot bare and instanced, depth limits 1 to 5, under the
+    PathTracer.  Whole frames, every sample."""
+    from raytracer_amd import flatten
+    from raytracer_amd.world import World
+    for k in range(6):
+        world = World(viewmode="parallel", buildfunction="fuzzpath_%d" % k, seed=1)
+        check_tiles_against_oracle(torch_gpu, world, flatten.flatten_world(world), 96, None, "fuzzpath_%d" % k)
+
+
 def test_shadow_walk_from_an_origin_on_a_split_plane(torch_gpu):
     """`fuzzmesh_2031`, a world of the hand-run sweep: an ambient-occlusion ray starts on the ground at an x that,
     rounded to single precision, equals a split plane of the teapot's shadow tree, and leaves the plane towards
